@@ -1,0 +1,195 @@
+/*
+ * voxelba.h — C ABI of the MI355X-native Voxel-SLAM local-mapping hot path (libvoxelba.so).
+ *
+ * The reference (Wangshihu12/Voxel-SLAM, /root/reference/VoxelSLAM/src) has no FFI/plugin boundary: the
+ * path is reached through C++ member calls on header-only classes.  Each entry point
+ * below names the reference interface it replaces (VM = voxel_map.hpp, VS = voxelslam.cpp,
+ * TL = tools.hpp, PI = preintegration.hpp).  include/voxelba_adapter.hpp wraps these calls back into
+ * the reference's class/method names (LidarFactor, Lidar_BA_Optimizer, LI_BA_Optimizer, ...).
+ *
+ * Conventions
+ *   - All numeric arrays are IEEE double, caller-owned, HOST memory unless a name ends in _dev.
+ *   - Every function returns an int status (VBA_OK = 0) where the reference would printf+exit(0)
+ *     (VM:401-402, VM:1490-1491) or silently return; no function throws.
+ *   - A context is re-entrant per handle: one HIP stream per vba_ctx, no process-wide mutable state
+ *     (the reference's globals VM:98-104, VM:500, VM:1046 are fields of vba_options / the context).
+ *   - The library has NO CPU compute fallback: without a HIP device vba_create fails with
+ *     VBA_ERR_NO_DEVICE.
+ *
+ * Flat layouts
+ *   cluster : [Pxx,Pxy,Pxz,Pyy,Pyz,Pzz, vx,vy,vz, N]    (10)   PointCluster TL:304-310 (P symmetric)
+ *   pose    : [R(9) row-major, p(3)]                    (12)   IMUST::R, IMUST::p  TL:139-140
+ *   state   : [t, R(9), p(3), v(3), bg(3), ba(3), g(3)] (25)   IMUST TL:135-144 (cov passed separately)
+ *   imu_pre : [R_delta(9) p_delta(3) v_delta(3) bg(3) ba(3) R_bg(9) p_bg(9) p_ba(9) v_bg(9) v_ba(9)
+ *              dtime dbg(3) dba(3) dbg_buf(3) dba_buf(3) cov(225)]  (304)   IMU_PRE PI:15-28
+ *   3x3 / NxN matrices are row-major; eigenvector matrices hold eigenvectors in COLUMNS (VM:193).
+ */
+#ifndef VOXELBA_H
+#define VOXELBA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBA_CLUSTER_LEN 10
+#define VBA_POSE_LEN 12
+#define VBA_STATE_LEN 25
+#define VBA_IMU_PRE_LEN 304
+#define VBA_DIM 15 /* TL:16 */
+#define VBA_MAX_WIN 16
+
+enum vba_status {
+  VBA_OK = 0,
+  VBA_ERR_NO_DEVICE = 1,       /* no HIP device / kernel image: the product has no CPU path */
+  VBA_ERR_BAD_ARG = 2,
+  VBA_ERR_UNSUPPORTED_WINDOW = 3,
+  VBA_ERR_TOO_FEW_VOXELS = 4,  /* Lidar_BA_Optimizer::only_residual "Too Less Voxel" exit(0), VM:399-403 */
+  VBA_ERR_OPT_STATE = 5,       /* OctoTree::margi "Error: opt_state" exit(0), VM:1488-1492 */
+  VBA_ERR_HIP = 6,
+  VBA_ERR_CAPACITY = 7
+};
+
+typedef struct vba_ctx vba_ctx;
+
+/* Replaces the process-wide configuration of the reference: voxel_size, min_eigen_value, max_layer,
+ * max_points, plane_eigen_value_thre, min_point (VM:98-104), imu_coef (VM:500), LocalBA/win_size and
+ * thread_num (VS:875-931).  plane_eigen_value_thre is passed ALREADY INVERTED as the reference stores
+ * it (VS:930-931). */
+typedef struct vba_options {
+  int win_size;                     /* LocalBA/win_size */
+  double voxel_size;                /* Odometry/voxel_size */
+  int max_layer;                    /* VM:100 */
+  int max_points;                   /* VM:101 */
+  double min_eigen_value;           /* VM:99 */
+  double plane_eigen_value_thre[4]; /* VM:104, inverted */
+  double min_point[4];              /* VM:98 */
+  double imu_coef;                  /* VM:500 */
+  int thread_num;                   /* only for the "#voxels < thread_num" early-return quirks (VM:2044, VS:1616, VS:1693) */
+  int device;                       /* HIP device ordinal, -1 = current */
+  void *stream;                     /* hipStream_t to run on, NULL = the context creates its own */
+  size_t max_voxels;                /* factor capacity hint (0 = grow on demand) */
+  size_t max_points_per_scan;       /* map capacity hint (0 = grow on demand) */
+} vba_options;
+
+void vba_default_options(vba_options *opt); /* values of config/avia.yaml:26-47 */
+int vba_create(const vba_options *opt, vba_ctx **out);
+void vba_destroy(vba_ctx *ctx);
+const char *vba_status_string(int status);
+const char *vba_last_error(vba_ctx *ctx);
+int vba_synchronize(vba_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Factor level — drop-in for class LidarFactor (VM:124-339).
+ * The factor store lives in HBM as SoA [field][frame][voxel].                        */
+
+/* LidarFactor::clear (VM:328-336) */
+int vba_factor_clear(vba_ctx *ctx);
+/* LidarFactor::push_voxel (VM:139-147), batched: n voxels appended.
+ * clusters [n][W][10], fix [n][10], coe [n], eig_val [n][3], eig_vec [n][9], pcr_add [n][10]. */
+int vba_factor_push_voxels(vba_ctx *ctx, int n, const double *clusters, const double *fix, const double *coe,
+                           const double *eig_val, const double *eig_vec, const double *pcr_add);
+/* plvec_voxels.size() (read by callers at VS:706) */
+int vba_factor_size(vba_ctx *ctx);
+/* LidarFactor::acc_evaluate2 (VM:150-282) over voxels [head,end): Hess (6W x 6W), JacT (6W), residual. */
+int vba_factor_acc_evaluate2(vba_ctx *ctx, const double *poses, int head, int end, double *Hess, double *JacT,
+                             double *residual);
+/* LidarFactor::evaluate_only_residual (VM:285-325) over [head,end); updates the device-side
+ * eig_values / eig_vectors / pcr_adds exactly as the reference does (VM:317-319). */
+int vba_factor_evaluate_only_residual(vba_ctx *ctx, const double *poses, int head, int end, double *residual);
+/* Public data members eig_values / eig_vectors / pcr_adds read by OctoTree::margi (VM:1495-1501) and
+ * motion_init (VS:737).  Any pointer may be NULL. */
+int vba_factor_read_back(vba_ctx *ctx, double *eig_val, double *eig_vec, double *pcr_add);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizers — drop-in for the three LM classes.                                                  */
+
+/* bool Lidar_BA_Optimizer::damping_iter(x_stats, voxhess, hess, resis, max_iter, is_display) (VM:422-497).
+ * poses [W][12] in/out; hess (6W)^2 out (may be NULL); resis2[2] = {first, last} appended values;
+ * thd_num = Lidar_BA_Optimizer::thd_num (VM:345) — only used for the V < thd_num check (VM:399).
+ * *is_converge receives the bool return value. */
+int vba_lidar_ba_damping_iter(vba_ctx *ctx, double *poses, double *hess, double *resis2, int max_iter, int thd_num,
+                              int *is_converge);
+
+/* void LI_BA_Optimizer::damping_iter(x_stats, voxhess, imus_factor, hess) (VM:624-713) when gravity == 0;
+ * void LI_BA_OptimizerGravity::damping_iter(x_stats, voxhess, imus_factor, resis, hess, max_iter) (VM:878-975)
+ * when gravity != 0.  states [W][25] in/out, imus [W-1][304] in/out (dbg/dba/dbg_buf/dba_buf are updated,
+ * PI:296-303), hess ((15W + 3*gravity)^2) out (may be NULL), resis2 out (gravity variant only, may be NULL). */
+int vba_li_ba_damping_iter(vba_ctx *ctx, double *states, double *imus, int gravity, int max_iter, double *hess,
+                           double *resis2);
+
+/* Optional iteration trace of the last damping_iter on this context: rows [r1, r2, u, v, q1] as used in each
+ * executed iteration.  Returns the number of rows written (<= max_rows). */
+int vba_last_lm_trace(vba_ctx *ctx, double *rows, int max_rows);
+
+/* IMU_PRE(bg, ba) + IMU_PRE::push_imu (PI:32-73) with the noise globals noiseMeas / noiseWalk /
+ * imupre_scale_gravity (PI:8-9) passed as diagonals: samples t[n], gyr[n][3], acc[n][3] -> imu_pre[304]. */
+int vba_imu_preintegrate(int n, const double *t, const double *gyr, const double *acc, const double *bg,
+                         const double *ba, const double *noise_meas_diag6, const double *noise_walk_diag6,
+                         double scale_gravity, double *imu_pre_out);
+/* IMU_PRE::give_evaluate (PI:137-212) / give_evaluate_g (PI:214-294): returns r^T cov^-1 r in *resid;
+ * jtj ((30|33)^2) and gg (30|33) are written when jac_enable != 0. */
+int vba_imu_give_evaluate(const double *imu_pre, const double *state1, const double *state2, int with_gravity,
+                          int jac_enable, double *jtj, double *gg, double *resid);
+
+/* ------------------------------------------------------------------------------------------------
+ * Map level — drop-in for the voxel hash map + octree of local mapping.                           */
+
+/* cut_voxel (VM:1896-1949) / cut_voxel_multi (VM:1964-2096) for one scan: pnt_body [n][3] body-frame
+ * points (pointVar::pnt), var [n][9] per-point covariance as produced by pvec_update (VH:242-265) or NULL,
+ * pose [12] = the scan's pose used for pw = R p + t (the pwld argument), win_count = frame index in the window.
+ * multi != 0 applies cut_voxel_multi's "#touched voxels < thread_num -> scan dropped" rule (VM:2044-2045). */
+int vba_map_cut_voxel(vba_ctx *ctx, int win_count, int n, const double *pnt_body, const double *var,
+                      const double *pose, int multi);
+/* cut_voxel(feat_map, PVec&, wdsize, jour) for fixed (already-world) points (VM:2108-2152). */
+int vba_map_cut_voxel_fix(vba_ctx *ctx, int n, const double *pnt_world, double jour);
+/* multi_recut (VS:1682-1737) when multi != 0, or the loop "recut + tras_opt over surf_map" of motion_init
+ * (VS:699-703) when multi == 0: OctoTree::recut (VM:1396-1456) on every root, then OctoTree::tras_opt
+ * (VM:1605-1638) fills the context's factor store (voxhess.clear() + win_size, VS:1918-1919, is implied). */
+int vba_map_recut(vba_ctx *ctx, int win_count, const double *poses, int multi);
+/* multi_margi (VS:1590-1679): OctoTree::margi (VM:1465-1598, mgsize = 1) on every root of the sliding map
+ * using the factor store's refined eig/pcr_add, then drops roots with !isexist from the sliding map. */
+int vba_map_margi(vba_ctx *ctx, int win_count, const double *poses);
+/* Ring-map rotation mp[i] = (mp[i] + mgsize) mod W (VS:2014-2019). */
+int vba_map_slide(vba_ctx *ctx, int mgsize);
+/* Destroys the map (system_reset / motion_init teardown, VS:650-661). */
+int vba_map_reset(vba_ctx *ctx);
+int vba_map_num_roots(vba_ctx *ctx);       /* surf_map.size() */
+int vba_map_num_slide_roots(vba_ctx *ctx); /* surf_map_slide.size() */
+/* Leaf dump for inspection / parity tests: 39 doubles per leaf
+ * [kx,ky,kz, layer, path, N_add, N_fix, is_plane, isexist, opt_state, eig_value(3), eig_vector(9), pcr_add(10),
+ *  plane.center(3), plane.normal(3), plane.radius].  out == NULL returns the leaf count. */
+int vba_map_dump_leaves(vba_ctx *ctx, double *out, int max_leaves);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: voxels are sharded by root-voxel hash bucket; each rank evaluates its
+ * shard and the packed [H | g | r] buffer is summed across ranks (the thread-sum of VM:571-581).
+ * The reduction itself is supplied by the host program (torch.distributed/RCCL all_reduce on the
+ * device buffer, stream-ordered on the context's stream).                                          */
+typedef int (*vba_allreduce_fn)(void *user, void *buf_dev, size_t n_doubles, void *stream);
+int vba_set_allreduce(vba_ctx *ctx, vba_allreduce_fn fn, void *user);
+/* Which rank owns root voxel (kx,ky,kz) out of n_ranks (pure function, usable without a device). */
+int vba_shard_owner(int64_t kx, int64_t ky, int64_t kz, int n_ranks);
+int vba_set_shard(vba_ctx *ctx, int rank, int n_ranks);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): average device time in microseconds of the named kernel family since
+ * the last reset, from hipEvents recorded on the context's stream around each launch.             */
+int vba_timing_enable(vba_ctx *ctx, int on);
+int vba_timing_reset(vba_ctx *ctx);
+/* name in {"residual","hessian","reduce","insert","recut","margi"}; returns launches in *count. */
+int vba_timing_get(vba_ctx *ctx, const char *name, double *total_us, int *count);
+
+/* LM building blocks on device state (used by bench.py to time exactly K LM iterations, and by the
+ * damping_iter entry points themselves): begin loads the poses, iterate runs one trip through the
+ * loop body VM:441-494 / VM:643-710, end copies the refined poses back. */
+int vba_lm_begin(vba_ctx *ctx, const double *poses, int thd_num);
+int vba_lm_iterate(vba_ctx *ctx, int *accepted, int *stop);
+int vba_lm_end(vba_ctx *ctx, double *poses, double *hess, double *resis2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXELBA_H */

@@ -1,0 +1,299 @@
+"""ctypes binding of libvoxelba.so (include/voxelba.h) plus thin Python mirrors of the reference classes
+``LidarFactor`` / ``Lidar_BA_Optimizer`` / ``LI_BA_Optimizer`` / ``LI_BA_OptimizerGravity`` (voxel_map.hpp:124-976)
+and of the voxel-map entry points (``cut_voxel`` / ``multi_recut`` / ``multi_margi``).
+
+The product has no CPU path: ``load()`` raises if the shared library is missing, ``Context()`` raises if no
+HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libvoxelba.so")
+_dp = C.POINTER(C.c_double)
+
+OK = 0
+ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED_WINDOW, ERR_TOO_FEW_VOXELS, ERR_OPT_STATE, ERR_HIP, ERR_CAPACITY = range(1, 8)
+
+EXPORTS = [
+    "vba_default_options", "vba_create", "vba_destroy", "vba_status_string", "vba_last_error", "vba_synchronize",
+    "vba_factor_clear", "vba_factor_push_voxels", "vba_factor_size", "vba_factor_acc_evaluate2",
+    "vba_factor_evaluate_only_residual", "vba_factor_read_back",
+    "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
+    "vba_imu_preintegrate", "vba_imu_give_evaluate",
+    "vba_map_cut_voxel", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_reset",
+    "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves",
+    "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
+    "vba_timing_enable", "vba_timing_reset", "vba_timing_get",
+    "vba_lm_begin", "vba_lm_iterate", "vba_lm_end",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("win_size", C.c_int), ("voxel_size", C.c_double), ("max_layer", C.c_int), ("max_points", C.c_int),
+        ("min_eigen_value", C.c_double), ("plane_eigen_value_thre", C.c_double * 4), ("min_point", C.c_double * 4),
+        ("imu_coef", C.c_double), ("thread_num", C.c_int), ("device", C.c_int), ("stream", C.c_void_p),
+        ("max_voxels", C.c_size_t), ("max_points_per_scan", C.c_size_t),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class VbaError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__("libvoxelba status %d: %s" % (status, msg))
+        self.status = status
+
+
+def build(force: bool = False) -> str:
+    """Compile libvoxelba.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    src = os.path.join(_PKG, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", src, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libvoxelba.so is missing (run __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.vba_status_string.restype = C.c_char_p
+        lib.vba_last_error.restype = C.c_char_p
+        lib.vba_shard_owner.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int]
+        _lib = lib
+    return _lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def default_options() -> Options:
+    o = Options()
+    load().vba_default_options(C.byref(o))
+    return o
+
+
+def options_from_workload(wl, stream=None) -> Options:
+    o = default_options()
+    o.win_size = wl.win_size
+    o.voxel_size = wl.voxel_size
+    o.max_layer = wl.max_layer
+    o.max_points = wl.max_points
+    o.min_eigen_value = wl.min_eigen_value
+    for i in range(4):
+        o.plane_eigen_value_thre[i] = wl.plane_thre[i]
+        o.min_point[i] = wl.min_point[i]
+    o.imu_coef = wl.imu_coef
+    if stream is not None:
+        o.stream = stream
+    return o
+
+
+def shard_owner(key3, n_ranks: int) -> int:
+    return load().vba_shard_owner(int(key3[0]), int(key3[1]), int(key3[2]), int(n_ranks))
+
+
+def imu_preintegrate(t, gyr, acc, bg, ba, noise_meas, noise_walk, scale_gravity=1.0):
+    t, gyr, acc, bg, ba, nm, nw = map(_c, (t, gyr, acc, bg, ba, noise_meas, noise_walk))
+    out = np.empty(304)
+    st = load().vba_imu_preintegrate(C.c_int(len(t)), _p(t), _p(gyr), _p(acc), _p(bg), _p(ba), _p(nm), _p(nw), C.c_double(scale_gravity), _p(out))
+    if st:
+        raise VbaError(st)
+    return out
+
+
+def imu_give_evaluate(imu, st1, st2, with_g=False, jac=True):
+    imu, st1, st2 = map(_c, (imu, st1, st2))
+    nb = 33 if with_g else 30
+    jtj = np.zeros((nb, nb)); gg = np.zeros(nb); r = C.c_double()
+    st = load().vba_imu_give_evaluate(_p(imu), _p(st1), _p(st2), C.c_int(int(with_g)), C.c_int(int(jac)), _p(jtj), _p(gg), C.byref(r))
+    if st:
+        raise VbaError(st)
+    return r.value, jtj, gg
+
+
+class Context:
+    """One vba_ctx: a HIP stream, the HBM factor store (``LidarFactor``) and the device voxel map."""
+
+    def __init__(self, opt: Options):
+        self.lib = load()
+        self.opt = opt
+        self.W = opt.win_size
+        h = C.c_void_p()
+        st = self.lib.vba_create(C.byref(opt), C.byref(h))
+        if st:
+            raise VbaError(st, self.lib.vba_status_string(st).decode())
+        self.h = h
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st:
+            raise VbaError(st, self.lib.vba_status_string(st).decode() + " | " + self.lib.vba_last_error(self.h).decode())
+
+    def synchronize(self):
+        self._chk(self.lib.vba_synchronize(self.h))
+
+    # ---- LidarFactor (voxel_map.hpp:124-339)
+    def clear(self):
+        self._chk(self.lib.vba_factor_clear(self.h))
+
+    def size(self) -> int:
+        return self.lib.vba_factor_size(self.h)
+
+    def push_voxels(self, clusters, fix, coe, eig_val, eig_vec, pcr_add):
+        a = [_c(x) for x in (clusters, fix, coe, eig_val, eig_vec, pcr_add)]
+        self._chk(self.lib.vba_factor_push_voxels(self.h, C.c_int(len(a[2])), *[_p(x) for x in a]))
+
+    def push_dict(self, f):
+        self.push_voxels(f["clusters"], f["fix"], f["coe"], f["eig_val"], f["eig_vec"], f["pcr_add"])
+
+    def acc_evaluate2(self, poses, head=0, end=None):
+        end = self.size() if end is None else end
+        poses = _c(poses); n = 6 * self.W
+        H = np.empty((n, n)); g = np.empty(n); r = C.c_double()
+        self._chk(self.lib.vba_factor_acc_evaluate2(self.h, _p(poses), C.c_int(head), C.c_int(end), _p(H), _p(g), C.byref(r)))
+        return H, g, r.value
+
+    def evaluate_only_residual(self, poses, head=0, end=None):
+        end = self.size() if end is None else end
+        poses = _c(poses); r = C.c_double()
+        self._chk(self.lib.vba_factor_evaluate_only_residual(self.h, _p(poses), C.c_int(head), C.c_int(end), C.byref(r)))
+        return r.value
+
+    def read_back(self):
+        n = self.size()
+        ev = np.empty((n, 3)); evec = np.empty((n, 9)); pa = np.empty((n, 10))
+        self._chk(self.lib.vba_factor_read_back(self.h, _p(ev), _p(evec), _p(pa)))
+        return ev, evec, pa
+
+    # ---- optimizers
+    def last_trace(self):
+        rows = np.zeros((64, 5))
+        n = self.lib.vba_last_lm_trace(self.h, _p(rows), C.c_int(64))
+        return rows[:n].copy()
+
+    def lidar_ba_damping_iter(self, poses, max_iter=3, thd_num=2):
+        """Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:422-497)."""
+        poses = _c(poses).copy(); n = 6 * self.W
+        H = np.empty((n, n)); resis = np.zeros(2); conv = C.c_int(0)
+        st = self.lib.vba_lidar_ba_damping_iter(self.h, _p(poses), _p(H), _p(resis), C.c_int(max_iter), C.c_int(thd_num), C.byref(conv))
+        if st == ERR_TOO_FEW_VOXELS:
+            return dict(poses=poses, hess=H, resis=resis, converge=False, status=-1, trace=self.last_trace())
+        self._chk(st)
+        return dict(poses=poses, hess=H, resis=resis, converge=bool(conv.value), status=0, trace=self.last_trace())
+
+    def li_ba_damping_iter(self, states, imus, gravity=False, max_iter=3):
+        """LI_BA_Optimizer::damping_iter (voxel_map.hpp:624-713) / LI_BA_OptimizerGravity::damping_iter (:878-975)."""
+        states = _c(states).copy(); imus = _c(imus).copy()
+        n = 15 * self.W + (3 if gravity else 0)
+        H = np.empty((n, n)); resis = np.zeros(2)
+        self._chk(self.lib.vba_li_ba_damping_iter(self.h, _p(states), _p(imus), C.c_int(int(gravity)), C.c_int(max_iter), _p(H), _p(resis)))
+        return dict(states=states, imus=imus, hess=H, resis=resis, trace=self.last_trace())
+
+    def lm_begin(self, poses, thd_num=2):
+        poses = _c(poses)
+        self._chk(self.lib.vba_lm_begin(self.h, _p(poses), C.c_int(thd_num)))
+
+    def lm_iterate(self):
+        acc = C.c_int(0); stop = C.c_int(0)
+        self._chk(self.lib.vba_lm_iterate(self.h, C.byref(acc), C.byref(stop)))
+        return bool(acc.value), bool(stop.value)
+
+    def lm_end(self):
+        n = 6 * self.W
+        poses = np.empty((self.W, 12)); H = np.empty((n, n)); resis = np.zeros(2)
+        self._chk(self.lib.vba_lm_end(self.h, _p(poses), _p(H), _p(resis)))
+        return poses, H, resis
+
+    # ---- voxel map
+    def cut_voxel(self, win_count, pnt_body, pose12, var=None, multi=False):
+        pnt_body = _c(pnt_body); pose12 = _c(pose12)
+        v = _c(var) if var is not None else None
+        self._chk(self.lib.vba_map_cut_voxel(self.h, C.c_int(win_count), C.c_int(len(pnt_body)), _p(pnt_body), _p(v), _p(pose12), C.c_int(int(multi))))
+
+    def cut_voxel_fix(self, pnt_world, jour=0.0):
+        pnt_world = _c(pnt_world)
+        self._chk(self.lib.vba_map_cut_voxel_fix(self.h, C.c_int(len(pnt_world)), _p(pnt_world), C.c_double(jour)))
+
+    def recut(self, win_count, poses, multi=False):
+        poses = _c(poses)
+        self._chk(self.lib.vba_map_recut(self.h, C.c_int(win_count), _p(poses), C.c_int(int(multi))))
+
+    def margi(self, win_count, poses):
+        poses = _c(poses)
+        self._chk(self.lib.vba_map_margi(self.h, C.c_int(win_count), _p(poses)))
+
+    def slide(self, mgsize=1):
+        self._chk(self.lib.vba_map_slide(self.h, C.c_int(mgsize)))
+
+    def map_reset(self):
+        self._chk(self.lib.vba_map_reset(self.h))
+
+    def num_roots(self):
+        return self.lib.vba_map_num_roots(self.h)
+
+    def num_slide_roots(self):
+        return self.lib.vba_map_num_slide_roots(self.h)
+
+    def dump_leaves(self):
+        n = self.lib.vba_map_dump_leaves(self.h, None, C.c_int(0))
+        out = np.zeros((max(n, 0), 39))
+        if n > 0:
+            self.lib.vba_map_dump_leaves(self.h, _p(out), C.c_int(n))
+        return out
+
+    # ---- multi-GPU / timing
+    def set_shard(self, rank, n_ranks):
+        self._chk(self.lib.vba_set_shard(self.h, C.c_int(rank), C.c_int(n_ranks)))
+
+    def set_allreduce(self, pyfunc):
+        """pyfunc(dev_ptr:int, n_doubles:int, stream:int) -> int; kept alive on the context."""
+        def tramp(user, buf, n, stream):
+            try:
+                return int(pyfunc(buf, n, stream) or 0)
+            except Exception:   # noqa: BLE001 - must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        self._chk(self.lib.vba_set_allreduce(self.h, self._cb, None))
+
+    def timing_enable(self, on=True):
+        self.lib.vba_timing_enable(self.h, C.c_int(int(on)))
+
+    def timing_reset(self):
+        self.lib.vba_timing_reset(self.h)
+
+    def timing_get(self, name):
+        tot = C.c_double(); cnt = C.c_int()
+        self.lib.vba_timing_get(self.h, name.encode(), C.byref(tot), C.byref(cnt))
+        return tot.value, cnt.value

@@ -1,0 +1,718 @@
+// libvoxelba.so — implementation of include/voxelba.h for MI355X (gfx950).
+// Host side: context / HBM store management, the three LM drivers (voxel_map.hpp:342-976) and the IMU factor;
+// device side: the kernels in vba_kernels_factor.hpp / vba_kernels_map.hpp.  No CPU compute fallback exists.
+#include "../../include/voxelba.h"
+
+#define VBA_MAX_WIN_DEV VBA_MAX_WIN
+#include "vba_kernels_factor.hpp"
+#include "vba_kernels_map.hpp"
+#include "vba_hostmath.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include <deque>
+
+using namespace vba;
+
+#define HIPCHK(ctx, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+      return VBA_ERR_HIP;                                                                        \
+    }                                                                                            \
+  } while (0)
+
+namespace {
+struct TimedSpan { hipEvent_t a, b; };
+}
+
+struct vba_ctx {
+  vba_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // factor store (HBM, SoA)
+  FactorView fv{};
+  int nvox = 0;   // voxels stored
+  int cap = 0;    // capacity = stride
+  double *d_poses = nullptr;     // [W][12]
+  double *d_partial = nullptr;   // workgroup partials
+  size_t partial_doubles = 0;
+  double *d_out = nullptr;       // reduced [H | g | r] (+ scalar residual slot at the end)
+  double *h_pin = nullptr;       // pinned host staging
+  size_t pin_doubles = 0;
+  void *d_stage = nullptr;       // AoS upload staging
+  size_t stage_bytes = 0;
+
+  // multi-GPU
+  vba_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+  int rank = 0, n_ranks = 1;
+
+  // timing
+  bool timing = false;
+  std::map<std::string, std::vector<TimedSpan>> spans;
+
+  // LM state (lm_begin / lm_iterate / lm_end)
+  struct {
+    bool active = false;
+    int thd_num = 2;
+    double u = 0.01, v = 2;
+    bool is_calc_hess = true;
+    int iter = 0;
+    double residual1 = 0, residual2 = 0;
+    std::vector<double> x, x_temp, Hess, JacT, hess_saved;
+    double resis_first = 0;
+  } lm;
+  std::vector<double> trace;
+
+  MapStore map;
+
+  void set_error(const std::string &s) { err = s; }
+};
+
+namespace {
+
+const int kMaxBlocksHess = 512;
+
+int nout_of(int W) { return 36 * W * W + 6 * W + 1; }
+
+void span_begin(vba_ctx *c, const char *name, TimedSpan &s) {
+  if (!c->timing) return;
+  hipEventCreate(&s.a); hipEventCreate(&s.b);
+  hipEventRecord(s.a, c->stream);
+}
+void span_end(vba_ctx *c, const char *name, TimedSpan &s) {
+  if (!c->timing) return;
+  hipEventRecord(s.b, c->stream);
+  c->spans[name].push_back(s);
+}
+
+int ensure_pin(vba_ctx *c, size_t n) {
+  if (n <= c->pin_doubles) return VBA_OK;
+  if (c->h_pin) hipHostFree(c->h_pin);
+  c->h_pin = nullptr; c->pin_doubles = 0;
+  HIPCHK(c, hipHostMalloc((void **)&c->h_pin, n * sizeof(double), hipHostMallocDefault));
+  c->pin_doubles = n;
+  return VBA_OK;
+}
+int ensure_stage(vba_ctx *c, size_t bytes) {
+  if (bytes <= c->stage_bytes) return VBA_OK;
+  if (c->d_stage) hipFree(c->d_stage);
+  c->d_stage = nullptr; c->stage_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->d_stage, bytes));
+  c->stage_bytes = bytes;
+  return VBA_OK;
+}
+
+// (re)allocate the SoA factor store with stride newcap, preserving the first nvox voxels
+int factor_reserve(vba_ctx *c, int need) {
+  if (need <= c->cap) return VBA_OK;
+  int newcap = c->cap ? c->cap : 4096;
+  while (newcap < need) newcap *= 2;
+  newcap = (newcap + 63) / 64 * 64;
+  const int W = c->opt.win_size;
+  FactorView n = c->fv;
+  n.vs = newcap; n.W = W;
+  const size_t rows[6] = {(size_t)10 * W, 10, 1, 3, 9, 10};
+  double **np[6] = {&n.cl, &n.fix, &n.coe, &n.eigval, &n.eigvec, &n.pcr};
+  double *op[6] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr};
+  for (int k = 0; k < 6; k++) {
+    HIPCHK(c, hipMalloc((void **)np[k], rows[k] * newcap * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(*np[k], 0, rows[k] * newcap * sizeof(double), c->stream));
+    if (c->nvox > 0 && op[k])
+      HIPCHK(c, hipMemcpy2DAsync(*np[k], (size_t)newcap * sizeof(double), op[k], (size_t)c->cap * sizeof(double),
+                                 (size_t)c->nvox * sizeof(double), rows[k], hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 6; k++) if (op[k]) hipFree(op[k]);
+  c->fv = n;
+  c->cap = newcap;
+  return VBA_OK;
+}
+
+int upload_poses(vba_ctx *c, const double *poses) {
+  const int W = c->opt.win_size;
+  int st = ensure_pin(c, 65536);
+  if (st) return st;
+  std::memcpy(c->h_pin, poses, (size_t)W * 12 * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_pin, (size_t)W * 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return VBA_OK;
+}
+
+template <int W>
+int launch_hessian_t(vba_ctx *c, int head, int end, int *nblocks_out) {
+  using C = HessCfg<W>;
+  const int ntiles = (end - head + C::TV - 1) / C::TV;
+  int nb = ntiles < kMaxBlocksHess ? ntiles : kMaxBlocksHess;
+  if (nb < 1) nb = 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void *)k_hessian<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_hessian<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, c->d_poses, head, end, ntiles, c->d_partial);
+  *nblocks_out = nb;
+  return VBA_OK;
+}
+
+int launch_hessian(vba_ctx *c, int head, int end, int *nb) {
+  switch (c->opt.win_size) {
+    case 2: return launch_hessian_t<2>(c, head, end, nb);
+    case 3: return launch_hessian_t<3>(c, head, end, nb);
+    case 4: return launch_hessian_t<4>(c, head, end, nb);
+    case 5: return launch_hessian_t<5>(c, head, end, nb);
+    case 6: return launch_hessian_t<6>(c, head, end, nb);
+    case 8: return launch_hessian_t<8>(c, head, end, nb);
+    case 10: return launch_hessian_t<10>(c, head, end, nb);
+    case 12: return launch_hessian_t<12>(c, head, end, nb);
+    case 16: return launch_hessian_t<16>(c, head, end, nb);
+    default: return VBA_ERR_UNSUPPORTED_WINDOW;
+  }
+}
+
+// device: d_out[0..nout) = [H | g | r] over voxels [head,end) (+ all-reduce across ranks when configured)
+int eval_hessian_dev(vba_ctx *c, const double *poses, int head, int end) {
+  const int W = c->opt.win_size, nout = nout_of(W);
+  int st = upload_poses(c, poses);
+  if (st) return st;
+  if (end <= head) {
+    HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)nout * sizeof(double), c->stream));
+  } else {
+    int nb = 0;
+    TimedSpan s1{}, s2{};
+    span_begin(c, "hessian", s1);
+    st = launch_hessian(c, head, end, &nb);
+    if (st) return st;
+    span_end(c, "hessian", s1);
+    span_begin(c, "reduce", s2);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((nout + 63) / 64), dim3(256), 0, c->stream, c->d_partial, nb, nout, c->d_out);
+    span_end(c, "reduce", s2);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (c->allreduce && c->n_ranks > 1) {
+    int rc = c->allreduce(c->allreduce_user, c->d_out, (size_t)nout, c->stream);
+    if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
+  }
+  return VBA_OK;
+}
+
+int eval_residual_dev(vba_ctx *c, const double *poses, int head, int end, double *d_scalar_out) {
+  int st = upload_poses(c, poses);
+  if (st) return st;
+  if (end <= head) {
+    HIPCHK(c, hipMemsetAsync(d_scalar_out, 0, sizeof(double), c->stream));
+  } else {
+    const int nb = (end - head + 63) / 64;
+    if ((size_t)nb > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
+    TimedSpan s1{}, s2{};
+    span_begin(c, "residual", s1);
+    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, c->d_poses, head, end, c->d_partial);
+    span_end(c, "residual", s1);
+    span_begin(c, "reduce", s2);
+    hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, c->stream, c->d_partial, nb, d_scalar_out);
+    span_end(c, "reduce", s2);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (c->allreduce && c->n_ranks > 1) {
+    int rc = c->allreduce(c->allreduce_user, d_scalar_out, 1, c->stream);
+    if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
+  }
+  return VBA_OK;
+}
+
+int ensure_partial(vba_ctx *c, size_t doubles) {
+  if (doubles <= c->partial_doubles) return VBA_OK;
+  if (c->d_partial) hipFree(c->d_partial);
+  c->d_partial = nullptr; c->partial_doubles = 0;
+  HIPCHK(c, hipMalloc((void **)&c->d_partial, doubles * sizeof(double)));
+  c->partial_doubles = doubles;
+  return VBA_OK;
+}
+
+// host copies of the reduced device results
+int fetch(vba_ctx *c, const double *d_src, size_t n, double *dst) {
+  int st = ensure_pin(c, n + 65536);
+  if (st) return st;
+  double *stage = c->h_pin + 32768;  // poses live in the first part
+  HIPCHK(c, hipMemcpyAsync(stage, d_src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(dst, stage, n * sizeof(double));
+  return VBA_OK;
+}
+
+// states <-> poses
+void states_to_poses(const double *states, int W, double *poses) {
+  for (int i = 0; i < W; i++) { std::memcpy(poses + 12 * i, states + 25 * i + 1, 9 * sizeof(double)); std::memcpy(poses + 12 * i + 9, states + 25 * i + 10, 3 * sizeof(double)); }
+}
+
+}  // namespace
+
+extern "C" {
+
+void vba_default_options(vba_options *o) {
+  std::memset(o, 0, sizeof(*o));
+  o->win_size = 10; o->voxel_size = 1.0; o->max_layer = 2; o->max_points = 100; o->min_eigen_value = 0.0025;
+  for (int i = 0; i < 4; i++) { o->plane_eigen_value_thre[i] = 0.25; o->min_point[i] = 5; }
+  o->imu_coef = 1e-4; o->thread_num = 5; o->device = -1; o->stream = nullptr;
+}
+
+const char *vba_status_string(int s) {
+  switch (s) {
+    case VBA_OK: return "ok";
+    case VBA_ERR_NO_DEVICE: return "no HIP device (libvoxelba has no CPU path)";
+    case VBA_ERR_BAD_ARG: return "bad argument";
+    case VBA_ERR_UNSUPPORTED_WINDOW: return "unsupported window size";
+    case VBA_ERR_TOO_FEW_VOXELS: return "too few voxels (reference: 'Too Less Voxel' exit)";
+    case VBA_ERR_OPT_STATE: return "opt_state out of range (reference: exit)";
+    case VBA_ERR_HIP: return "HIP runtime error";
+    case VBA_ERR_CAPACITY: return "capacity exceeded";
+    default: return "unknown";
+  }
+}
+
+int vba_create(const vba_options *opt, vba_ctx **out) {
+  if (!opt || !out) return VBA_ERR_BAD_ARG;
+  *out = nullptr;
+  if (opt->win_size < 2 || opt->win_size > VBA_MAX_WIN) return VBA_ERR_UNSUPPORTED_WINDOW;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VBA_ERR_NO_DEVICE;
+  vba_ctx *c = new vba_ctx();
+  c->opt = *opt;
+  if (opt->device >= 0) {
+    if (hipSetDevice(opt->device) != hipSuccess) { delete c; return VBA_ERR_NO_DEVICE; }
+    c->device = opt->device;
+  } else {
+    hipGetDevice(&c->device);
+  }
+  if (opt->stream) { c->stream = (hipStream_t)opt->stream; c->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VBA_ERR_HIP; }
+    c->own_stream = true;
+  }
+  const int W = opt->win_size, nout = nout_of(W);
+  c->fv.W = W;
+  if (hipMalloc((void **)&c->d_poses, (size_t)VBA_MAX_WIN * 12 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&c->d_out, ((size_t)nout + 64) * sizeof(double)) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
+  if (ensure_partial(c, (size_t)kMaxBlocksHess * nout) != VBA_OK || ensure_pin(c, 65536 + (size_t)nout + 1024) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
+  if (opt->max_voxels && factor_reserve(c, (int)opt->max_voxels) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
+  map_init(c->map, c->opt);
+  *out = c;
+  return VBA_OK;
+}
+
+void vba_destroy(vba_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  map_free(c->map);
+  double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out};
+  for (double *q : p) if (q) hipFree(q);
+  if (c->d_stage) hipFree(c->d_stage);
+  if (c->h_pin) hipHostFree(c->h_pin);
+  for (auto &kv : c->spans) for (auto &s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *vba_last_error(vba_ctx *c) { return c ? c->err.c_str() : ""; }
+int vba_synchronize(vba_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return VBA_OK; }
+
+// ---------------------------------------------------------------- factor level
+int vba_factor_clear(vba_ctx *c) { c->nvox = 0; return VBA_OK; }
+int vba_factor_size(vba_ctx *c) { return c->nvox; }
+
+int vba_factor_push_voxels(vba_ctx *c, int n, const double *clusters, const double *fix, const double *coe, const double *eig_val,
+                           const double *eig_vec, const double *pcr_add) {
+  if (n < 0) return VBA_ERR_BAD_ARG;
+  if (n == 0) return VBA_OK;
+  const int W = c->opt.win_size;
+  int st = factor_reserve(c, c->nvox + n);
+  if (st) return st;
+  const size_t per = (size_t)10 * W + 33;
+  st = ensure_stage(c, per * n * sizeof(double));
+  if (st) return st;
+  double *d = (double *)c->d_stage;
+  double *d_cl = d, *d_fix = d_cl + (size_t)n * W * 10, *d_coe = d_fix + (size_t)n * 10, *d_ev = d_coe + n, *d_evec = d_ev + (size_t)n * 3,
+         *d_pcr = d_evec + (size_t)n * 9;
+  HIPCHK(c, hipMemcpyAsync(d_cl, clusters, (size_t)n * W * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_fix, fix, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_coe, coe, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ev, eig_val, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_evec, eig_vec, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_pcr, pcr_add, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const long long tot = (long long)n * per;
+  int nb = (int)((tot + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_aos_to_soa, dim3(nb), dim3(256), 0, c->stream, c->fv, c->nvox, n, d_cl, d_fix, d_coe, d_ev, d_evec, d_pcr);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // caller's arrays may go away
+  c->nvox += n;
+  return VBA_OK;
+}
+
+int vba_factor_acc_evaluate2(vba_ctx *c, const double *poses, int head, int end, double *Hess, double *JacT, double *residual) {
+  if (head < 0 || end > c->nvox || head > end) return VBA_ERR_BAD_ARG;
+  const int W = c->opt.win_size, n = 6 * W, nout = nout_of(W);
+  int st = eval_hessian_dev(c, poses, head, end);
+  if (st) return st;
+  std::vector<double> buf(nout);
+  st = fetch(c, c->d_out, nout, buf.data());
+  if (st) return st;
+  if (Hess) std::memcpy(Hess, buf.data(), (size_t)n * n * sizeof(double));
+  if (JacT) std::memcpy(JacT, buf.data() + (size_t)n * n, (size_t)n * sizeof(double));
+  if (residual) *residual = buf[(size_t)n * n + n];
+  return VBA_OK;
+}
+
+int vba_factor_evaluate_only_residual(vba_ctx *c, const double *poses, int head, int end, double *residual) {
+  if (head < 0 || end > c->nvox || head > end) return VBA_ERR_BAD_ARG;
+  const int nout = nout_of(c->opt.win_size);
+  double *d_r = c->d_out + nout + 8;
+  int st = eval_residual_dev(c, poses, head, end, d_r);
+  if (st) return st;
+  double r = 0;
+  st = fetch(c, d_r, 1, &r);
+  if (st) return st;
+  if (residual) *residual = r;
+  return VBA_OK;
+}
+
+int vba_factor_read_back(vba_ctx *c, double *eig_val, double *eig_vec, double *pcr_add) {
+  const int n = c->nvox;
+  if (n == 0) return VBA_OK;
+  int st = ensure_stage(c, (size_t)n * 22 * sizeof(double));
+  if (st) return st;
+  double *d = (double *)c->d_stage;
+  double *d_ev = d, *d_evec = d + (size_t)n * 3, *d_pcr = d_evec + (size_t)n * 9;
+  int nb = (int)(((long long)n * 22 + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_soa_to_aos_out, dim3(nb), dim3(256), 0, c->stream, c->fv, n, d_ev, d_evec, d_pcr);
+  HIPCHK(c, hipGetLastError());
+  if (eig_val) HIPCHK(c, hipMemcpyAsync(eig_val, d_ev, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (eig_vec) HIPCHK(c, hipMemcpyAsync(eig_vec, d_evec, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (pcr_add) HIPCHK(c, hipMemcpyAsync(pcr_add, d_pcr, (size_t)n * 10 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- Lidar_BA_Optimizer (VM:342-498)
+int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
+  const int W = c->opt.win_size, n = 6 * W;
+  auto &L = c->lm;
+  L.active = true; L.thd_num = thd_num; L.u = 0.01; L.v = 2; L.is_calc_hess = true; L.iter = 0;
+  L.x.assign(poses, poses + (size_t)W * 12);
+  L.x_temp = L.x;
+  L.Hess.assign((size_t)n * n, 0.0); L.JacT.assign(n, 0.0); L.hess_saved.assign((size_t)n * n, 0.0);
+  L.residual1 = L.residual2 = 0; L.resis_first = 0;
+  c->trace.clear();
+  return VBA_OK;
+}
+
+// One trip through the loop body VM:441-494.
+int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
+  auto &L = c->lm;
+  if (!L.active) return VBA_ERR_BAD_ARG;
+  const int W = c->opt.win_size, n = 6 * W, nout = nout_of(W), V = c->nvox;
+  int st;
+  if (L.is_calc_hess) {                                               // VM:443-447 (divide_thread over all voxels)
+    st = eval_hessian_dev(c, L.x.data(), 0, V);
+    if (st) return st;
+    std::vector<double> buf(nout);
+    st = fetch(c, c->d_out, nout, buf.data());
+    if (st) return st;
+    std::memcpy(L.Hess.data(), buf.data(), (size_t)n * n * sizeof(double));
+    std::memcpy(L.JacT.data(), buf.data() + (size_t)n * n, (size_t)n * sizeof(double));
+    L.residual1 = buf[(size_t)n * n + n];
+    L.hess_saved = L.Hess;                                            // *hess = Hess
+  }
+  if (L.iter == 0) L.resis_first = L.residual1;                       // VM:449-450
+  double *H = L.Hess.data(), *g = L.JacT.data();
+  for (int r = 0; r < 6; r++) for (int k = 0; k < n; k++) { H[r * n + k] = 0; H[k * n + r] = 0; }   // VM:452-455
+  for (int r = 0; r < 6; r++) { H[r * n + r] = 1; g[r] = 0; }
+  std::vector<double> A(H, H + (size_t)n * n), rhs(n), dxi(n);
+  for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += L.u * H[(size_t)r * n + r]; rhs[r] = -g[r]; }     // VM:457-458
+  vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), n);
+  for (int j = 0; j < W; j++) {                                       // VM:460-464
+    double E[9];
+    vbh::so3_exp(&dxi[6 * j], E);
+    vbh::m3_mul(&L.x[12 * j], E, &L.x_temp[12 * j]);
+    for (int k = 0; k < 3; k++) L.x_temp[12 * j + 9 + k] = L.x[12 * j + 9 + k] + dxi[6 * j + 3 + k];
+  }
+  double q1 = 0;
+  for (int r = 0; r < n; r++) q1 += dxi[r] * (L.u * H[(size_t)r * n + r] * dxi[r] - g[r]);
+  q1 *= 0.5;                                                          // VM:465
+  if (V < L.thd_num) return VBA_ERR_TOO_FEW_VOXELS;                   // VM:399-403
+  double *d_r = c->d_out + nout + 8;
+  st = eval_residual_dev(c, L.x_temp.data(), 0, V, d_r);              // VM:467
+  if (st) return st;
+  st = fetch(c, d_r, 1, &L.residual2);
+  if (st) return st;
+  double q = L.residual1 - L.residual2;
+  const double tr[5] = {L.residual1, L.residual2, L.u, L.v, q1};
+  c->trace.insert(c->trace.end(), tr, tr + 5);
+  bool acc = false;
+  if (q > 0) {                                                        // VM:473-483
+    L.x = L.x_temp;
+    const double one_three = 1.0 / 3;
+    q = q / q1;
+    L.v = 2;
+    q = 1 - std::pow(2 * q - 1, 3);
+    L.u *= (q < one_three ? one_three : q);
+    L.is_calc_hess = true;
+    acc = true;
+  } else {                                                            // VM:484-490
+    L.u = L.u * L.v;
+    L.v = 2 * L.v;
+    L.is_calc_hess = false;
+  }
+  L.iter++;
+  if (accepted) *accepted = acc ? 1 : 0;
+  if (stop) *stop = (std::fabs((L.residual1 - L.residual2) / L.residual1) < 1e-6) ? 1 : 0;   // VM:492-493
+  return VBA_OK;
+}
+
+int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
+  auto &L = c->lm;
+  if (!L.active) return VBA_ERR_BAD_ARG;
+  const int W = c->opt.win_size, n = 6 * W;
+  if (poses) std::memcpy(poses, L.x.data(), (size_t)W * 12 * sizeof(double));
+  if (hess) std::memcpy(hess, L.hess_saved.data(), (size_t)n * n * sizeof(double));
+  if (resis2) { resis2[0] = L.resis_first; resis2[1] = L.residual2; }
+  L.active = false;
+  return VBA_OK;
+}
+
+int vba_lidar_ba_damping_iter(vba_ctx *c, double *poses, double *hess, double *resis2, int max_iter, int thd_num, int *is_converge) {
+  int st = vba_lm_begin(c, poses, thd_num);
+  if (st) return st;
+  bool conv = true;
+  for (int i = 0; i < max_iter; i++) {
+    int acc = 0, stop = 0;
+    st = vba_lm_iterate(c, &acc, &stop);
+    if (st) { c->lm.active = false; return st; }
+    if (!acc) conv = false;                                           // VM:489
+    if (stop) break;
+  }
+  if (is_converge) *is_converge = conv ? 1 : 0;
+  return vba_lm_end(c, poses, hess, resis2);
+}
+
+int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
+  int n = (int)(c->trace.size() / 5);
+  if (n > max_rows) n = max_rows;
+  if (rows) std::memcpy(rows, c->trace.data(), (size_t)n * 5 * sizeof(double));
+  return n;
+}
+
+// ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity (VM:504-976)
+int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
+  const int W = c->opt.win_size, n6 = 6 * W, nout = nout_of(W), V = c->nvox;
+  const int DIM = VBA_DIM;
+  const int imu_leng = W * DIM + (gravity ? 3 : 0);
+  const int nb = gravity ? 33 : 30;
+  const double imu_coef = c->opt.imu_coef;
+  vbh::State *xs = reinterpret_cast<vbh::State *>(states);
+  vbh::ImuPre *fac = reinterpret_cast<vbh::ImuPre *>(imus);
+  std::vector<vbh::State> x(xs, xs + W), xt(xs, xs + W);
+  std::vector<double> Hess((size_t)imu_leng * imu_leng), JacT(imu_leng), dxi(imu_leng), saved((size_t)imu_leng * imu_leng, 0.0);
+  std::vector<double> jtj((size_t)nb * nb), gg(nb), lid(nout), poses((size_t)W * 12);
+  double u = 0.01, v = 2, residual1 = 0, residual2 = 0, resis_first = 0;
+  bool is_calc_hess = true;
+  if (!gravity) max_iter = 3;                                         // VM:643
+  const int gauge = gravity ? 6 : DIM;                                // VM:653-656 vs VM:906-909
+  c->trace.clear();
+  auto imu_resid = [&](std::vector<vbh::State> &s) {                  // VM:605-607 / VM:851-854
+    double r = 0;
+    for (int i = 0; i < W - 1; i++) r += vbh::imu_evaluate(fac[i], s[i], s[i + 1], gravity != 0, false, nullptr, nullptr);
+    return r * (imu_coef * 0.5);
+  };
+  for (int it = 0; it < max_iter; it++) {
+    if (is_calc_hess) {                                               // divide_thread VM:519-584 / VM:746-825
+      states_to_poses(reinterpret_cast<double *>(x.data()), W, poses.data());
+      int st = eval_hessian_dev(c, poses.data(), 0, V);               // device pass runs while the host does the IMU part
+      if (st) return st;
+      std::fill(Hess.begin(), Hess.end(), 0.0); std::fill(JacT.begin(), JacT.end(), 0.0);
+      double residual = 0;
+      for (int i = 0; i < W - 1; i++) {
+        residual += vbh::imu_evaluate(fac[i], x[i], x[i + 1], gravity != 0, true, jtj.data(), gg.data());
+        for (int r = 0; r < 2 * DIM; r++) {
+          for (int k = 0; k < 2 * DIM; k++) Hess[(size_t)(i * DIM + r) * imu_leng + i * DIM + k] += jtj[(size_t)r * nb + k];
+          JacT[i * DIM + r] += gg[r];
+        }
+        if (gravity) {                                                // VM:788-795
+          for (int r = 0; r < 2 * DIM; r++)
+            for (int k = 0; k < 3; k++) {
+              Hess[(size_t)(i * DIM + r) * imu_leng + imu_leng - 3 + k] += jtj[(size_t)r * nb + 2 * DIM + k];
+              Hess[(size_t)(imu_leng - 3 + k) * imu_leng + i * DIM + r] += jtj[(size_t)(2 * DIM + k) * nb + r];
+            }
+          for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) Hess[(size_t)(imu_leng - 3 + r) * imu_leng + imu_leng - 3 + k] += jtj[(size_t)(2 * DIM + r) * nb + 2 * DIM + k];
+            JacT[imu_leng - 3 + r] += gg[2 * DIM + r];
+          }
+        }
+      }
+      for (double &h : Hess) h *= imu_coef;                           // VM:565-567
+      for (double &j : JacT) j *= imu_coef;
+      residual *= (imu_coef * 0.5);
+      st = fetch(c, c->d_out, nout, lid.data());
+      if (st) return st;
+      for (int i = 0; i < W; i++) {                                   // hess_plus VM:509-517
+        for (int r = 0; r < 6; r++) JacT[i * DIM + r] += lid[(size_t)n6 * n6 + i * 6 + r];
+        for (int j = 0; j < W; j++)
+          for (int r = 0; r < 6; r++)
+            for (int k = 0; k < 6; k++) Hess[(size_t)(i * DIM + r) * imu_leng + j * DIM + k] += lid[(size_t)(i * 6 + r) * n6 + j * 6 + k];
+      }
+      residual1 = residual + lid[(size_t)n6 * n6 + n6];
+      saved = Hess;                                                   // *hess = Hess (before gauge fixing, VM:650)
+    }
+    if (it == 0) resis_first = residual1;                             // VM:902-903
+    for (int r = 0; r < gauge; r++) for (int k = 0; k < imu_leng; k++) { Hess[(size_t)r * imu_leng + k] = 0; Hess[(size_t)k * imu_leng + r] = 0; }
+    for (int r = 0; r < gauge; r++) { Hess[(size_t)r * imu_leng + r] = 1; JacT[r] = 0; }
+    std::vector<double> A(Hess), rhs(imu_leng);
+    for (int r = 0; r < imu_leng; r++) { A[(size_t)r * imu_leng + r] += u * Hess[(size_t)r * imu_leng + r]; rhs[r] = -JacT[r]; }
+    vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), imu_leng);   // VM:659 / VM:918
+    if (gravity) for (int k = 0; k < 3; k++) xt[0].g[k] += dxi[imu_leng - 3 + k];     // VM:921 (accumulates on x_stats_temp)
+    for (int j = 0; j < W; j++) {                                     // VM:661-668 / VM:923-931
+      double E[9];
+      vbh::so3_exp(&dxi[DIM * j], E);
+      vbh::m3_mul(x[j].R, E, xt[j].R);
+      for (int k = 0; k < 3; k++) {
+        xt[j].p[k] = x[j].p[k] + dxi[DIM * j + 3 + k];
+        xt[j].v[k] = x[j].v[k] + dxi[DIM * j + 6 + k];
+        xt[j].bg[k] = x[j].bg[k] + dxi[DIM * j + 9 + k];
+        xt[j].ba[k] = x[j].ba[k] + dxi[DIM * j + 12 + k];
+        if (gravity) xt[j].g[k] = xt[0].g[k];
+      }
+    }
+    for (int j = 0; j < W - 1; j++) {                                 // IMU_PRE::update_state PI:296-303
+      for (int k = 0; k < 3; k++) {
+        fac[j].dbg_buf[k] = fac[j].dbg[k]; fac[j].dba_buf[k] = fac[j].dba[k];
+        fac[j].dbg[k] += dxi[DIM * j + 9 + k]; fac[j].dba[k] += dxi[DIM * j + 12 + k];
+      }
+    }
+    double q1 = 0;
+    for (int r = 0; r < imu_leng; r++) q1 += dxi[r] * (u * Hess[(size_t)r * imu_leng + r] * dxi[r] - JacT[r]);
+    q1 *= 0.5;
+    states_to_poses(reinterpret_cast<double *>(xt.data()), W, poses.data());
+    double *d_r = c->d_out + nout + 8;
+    int st = eval_residual_dev(c, poses.data(), 0, V, d_r);           // only_residual VM:586-622 / VM:831-870
+    if (st) return st;
+    const double r_imu = imu_resid(xt);
+    double r_lid = 0;
+    st = fetch(c, d_r, 1, &r_lid);
+    if (st) return st;
+    residual2 = r_imu + r_lid;
+    double q = residual1 - residual2;
+    const double tr[5] = {residual1, residual2, u, v, q1};
+    c->trace.insert(c->trace.end(), tr, tr + 5);
+    if (q > 0) {
+      x = xt;
+      const double one_three = 1.0 / 3;
+      q = q / q1;
+      v = 2;
+      q = 1 - std::pow(2 * q - 1, 3);
+      u *= (q < one_three ? one_three : q);
+      is_calc_hess = true;
+    } else {
+      u = u * v;
+      v = 2 * v;
+      is_calc_hess = false;
+      for (int j = 0; j < W - 1; j++)
+        for (int k = 0; k < 3; k++) { fac[j].dbg[k] = fac[j].dbg_buf[k]; fac[j].dba[k] = fac[j].dba_buf[k]; }   // VM:701-705
+    }
+    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+  }
+  std::memcpy(states, x.data(), (size_t)W * 25 * sizeof(double));
+  if (hess) std::memcpy(hess, saved.data(), saved.size() * sizeof(double));
+  if (gravity && resis2) { resis2[0] = resis_first; resis2[1] = residual2; }
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- IMU factor (host)
+int vba_imu_preintegrate(int n, const double *t, const double *gyr, const double *acc, const double *bg, const double *ba,
+                         const double *nm6, const double *nw6, double scale_gravity, double *out) {
+  if (n < 1 || !t || !gyr || !acc || !out) return VBA_ERR_BAD_ARG;
+  vbh::ImuPre m;
+  vbh::imu_init(m, bg, ba);
+  vbh::imu_push(m, n, t, gyr, acc, nm6, nw6, scale_gravity);
+  std::memcpy(out, &m, sizeof(m));
+  return VBA_OK;
+}
+int vba_imu_give_evaluate(const double *imu_pre, const double *s1, const double *s2, int with_gravity, int jac_enable, double *jtj,
+                          double *gg, double *resid) {
+  if (!imu_pre || !s1 || !s2) return VBA_ERR_BAD_ARG;
+  const double r = vbh::imu_evaluate(*reinterpret_cast<const vbh::ImuPre *>(imu_pre), *reinterpret_cast<const vbh::State *>(s1),
+                                     *reinterpret_cast<const vbh::State *>(s2), with_gravity != 0, jac_enable != 0, jtj, gg);
+  if (resid) *resid = r;
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU plumbing
+int vba_set_allreduce(vba_ctx *c, vba_allreduce_fn fn, void *user) { c->allreduce = fn; c->allreduce_user = user; return VBA_OK; }
+int vba_shard_owner(int64_t kx, int64_t ky, int64_t kz, int n_ranks) {
+  if (n_ranks <= 1) return 0;
+  return (int)(vba::shard_bucket(kx, ky, kz) * (uint64_t)n_ranks >> 16);   // contiguous bucket ranges per rank
+}
+int vba_set_shard(vba_ctx *c, int rank, int n_ranks) {
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return VBA_ERR_BAD_ARG;
+  c->rank = rank; c->n_ranks = n_ranks;
+  c->map.rank = rank; c->map.n_ranks = n_ranks;
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- timing
+int vba_timing_enable(vba_ctx *c, int on) { c->timing = on != 0; return VBA_OK; }
+int vba_timing_reset(vba_ctx *c) {
+  hipStreamSynchronize(c->stream);
+  for (auto &kv : c->spans) for (auto &s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+  c->spans.clear();
+  return VBA_OK;
+}
+int vba_timing_get(vba_ctx *c, const char *name, double *total_us, int *count) {
+  hipStreamSynchronize(c->stream);
+  double tot = 0; int n = 0;
+  auto it = c->spans.find(name);
+  if (it != c->spans.end())
+    for (auto &s : it->second) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { tot += (double)ms * 1000.0; n++; } }
+  if (total_us) *total_us = tot;
+  if (count) *count = n;
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- map level (vba_kernels_map.hpp)
+int vba_map_cut_voxel(vba_ctx *c, int win_count, int n, const double *pnt_body, const double *var, const double *pose, int multi) {
+  return map_cut_voxel(c->map, c->stream, win_count, n, pnt_body, var, pose, multi != 0, c->err);
+}
+int vba_map_cut_voxel_fix(vba_ctx *c, int n, const double *pnt_world, double jour) {
+  return map_cut_voxel_fix(c->map, c->stream, n, pnt_world, jour, c->err);
+}
+int vba_map_recut(vba_ctx *c, int win_count, const double *poses, int multi) {
+  int nf = 0;
+  int st = map_recut(c->map, c->stream, win_count, poses, multi != 0, c->err, &nf);
+  if (st) return st;
+  // tras_opt: the map writes the planar leaves straight into the SoA factor store (no host round trip)
+  c->nvox = 0;
+  st = factor_reserve(c, nf > 0 ? nf : 1);
+  if (st) return st;
+  st = map_extract_factors(c->map, c->stream, c->fv, c->err, &nf);
+  if (st) return st;
+  c->nvox = nf;
+  return VBA_OK;
+}
+int vba_map_margi(vba_ctx *c, int win_count, const double *poses) { return map_margi(c->map, c->stream, win_count, poses, c->fv, c->nvox, c->err); }
+int vba_map_slide(vba_ctx *c, int mgsize) { return map_slide(c->map, mgsize); }
+int vba_map_reset(vba_ctx *c) { return map_reset(c->map, c->stream, c->err); }
+int vba_map_num_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, false); }
+int vba_map_num_slide_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, true); }
+int vba_map_dump_leaves(vba_ctx *c, double *out, int max_leaves) { return map_dump_leaves(c->map, c->stream, out, max_leaves, c->err); }
+
+}  // extern "C"

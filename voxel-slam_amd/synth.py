@@ -234,7 +234,7 @@ def pack_clusters(P: np.ndarray, v: np.ndarray, N: np.ndarray) -> np.ndarray:
     return out
 
 
-def root_factors(points: List[np.ndarray], R: np.ndarray, p: np.ndarray, wl: Workload) -> dict:
+def root_factors(points: List[np.ndarray], R: np.ndarray, p: np.ndarray, wl: Workload, with_keys: bool = False) -> dict:
     W = len(points)
     keys, frames, pw_all, pb_all = [], [], [], []
     for i in range(W):
@@ -245,7 +245,7 @@ def root_factors(points: List[np.ndarray], R: np.ndarray, p: np.ndarray, wl: Wor
         pb_all.append(points[i])
     keys = np.concatenate(keys); frames = np.concatenate(frames)
     pw_all = np.concatenate(pw_all); pb_all = np.concatenate(pb_all)
-    _, vid = np.unique(keys, axis=0, return_inverse=True)
+    ukeys, vid = np.unique(keys, axis=0, return_inverse=True)
     vid = vid.ravel()
     V = int(vid.max()) + 1
     Pw = np.zeros((V, 3, 3)); vw = np.zeros((V, 3)); Nw = np.zeros(V)
@@ -263,7 +263,7 @@ def root_factors(points: List[np.ndarray], R: np.ndarray, p: np.ndarray, wl: Wor
     with np.errstate(divide="ignore", invalid="ignore"):
         plane = ok & (lam[:, 0] < wl.min_eigen_value) & (lam[:, 0] / lam[:, 2] < wl.plane_thre[0]) & (lam[:, 0] / lam[:, 1] <= 0.12)
     sel = np.nonzero(plane)[0]
-    return dict(
+    out = dict(
         clusters=np.ascontiguousarray(pack_clusters(Pb[sel], vb[sel], Nb[sel])),      # [V][W][10]
         fix=np.zeros((len(sel), 10)),
         coe=np.ones(len(sel)),
@@ -271,3 +271,6 @@ def root_factors(points: List[np.ndarray], R: np.ndarray, p: np.ndarray, wl: Wor
         eig_vec=np.ascontiguousarray(U[sel].reshape(len(sel), 9)),                    # row-major, columns = eigenvectors
         pcr_add=np.ascontiguousarray(pack_clusters(Pw[sel], vw[sel], Nw[sel])),
     )
+    if with_keys:
+        out["keys"] = np.ascontiguousarray(ukeys[sel])
+    return out
