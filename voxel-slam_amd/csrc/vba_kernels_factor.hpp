@@ -178,17 +178,23 @@ __global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__r
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-// out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 64 outputs x 4 partial groups.
+// out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 16 outputs x 16 partial groups,
+// so ~nout/16 workgroups keep every CU busy on the (nb x nout) partial slab.
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nb, int nout, double *__restrict__ out) {
   __shared__ double s[256];
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + lane;
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + j;
   double acc = 0.0;
-  if (j < nout)
-    for (int b = q; b < nb; b += 4) acc += partial[(size_t)b * nout + j];
+  if (o < nout)
+    for (int b = q; b < nb; b += 16) acc += partial[(size_t)b * nout + o];
   s[threadIdx.x] = acc;
   __syncthreads();
-  if (q == 0 && j < nout) out[j] = (s[lane] + s[64 + lane]) + (s[128 + lane] + s[192 + lane]);
+  if (q == 0 && o < nout) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += s[16 * k + j];
+    out[o] = t;
+  }
 }
 
 // scalar version: out[0] = sum partial[0..nb)  (one workgroup, fixed tree)

@@ -81,7 +81,7 @@ struct vba_ctx {
 
 namespace {
 
-const int kMaxBlocksHess = 512;
+const int kMaxBlocksHess = 256;
 
 int nout_of(int W) { return 36 * W * W + 6 * W + 1; }
 
@@ -194,7 +194,7 @@ int eval_hessian_dev(vba_ctx *c, const double *poses, int head, int end) {
     if (st) return st;
     span_end(c, "hessian", s1);
     span_begin(c, "reduce", s2);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((nout + 63) / 64), dim3(256), 0, c->stream, c->d_partial, nb, nout, c->d_out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((nout + 15) / 16), dim3(256), 0, c->stream, c->d_partial, nb, nout, c->d_out);
     span_end(c, "reduce", s2);
     HIPCHK(c, hipGetLastError());
   }
