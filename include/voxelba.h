@@ -140,7 +140,8 @@ int vba_imu_give_evaluate(const double *imu_pre, const double *state1, const dou
 /* cut_voxel (VM:1896-1949) / cut_voxel_multi (VM:1964-2096) for one scan: pnt_body [n][3] body-frame
  * points (pointVar::pnt), var [n][9] per-point covariance as produced by pvec_update (VH:242-265) or NULL,
  * pose [12] = the scan's pose used for pw = R p + t (the pwld argument), win_count = frame index in the window.
- * multi != 0 applies cut_voxel_multi's "#touched voxels < thread_num -> scan dropped" rule (VM:2044-2045). */
+ * multi != 0 applies cut_voxel_multi's "#touched voxels < thread_num -> scan dropped" rule (VM:2044-2045).
+ * pnt_body / var may point to HOST or DEVICE (HBM) memory; device buffers are consumed in place. */
 int vba_map_cut_voxel(vba_ctx *ctx, int win_count, int n, const double *pnt_body, const double *var,
                       const double *pose, int multi);
 /* cut_voxel(feat_map, PVec&, wdsize, jour) for fixed (already-world) points (VM:2108-2152). */
@@ -150,8 +151,9 @@ int vba_map_cut_voxel_fix(vba_ctx *ctx, int n, const double *pnt_world, double j
  * (VM:1605-1638) fills the context's factor store (voxhess.clear() + win_size, VS:1918-1919, is implied). */
 int vba_map_recut(vba_ctx *ctx, int win_count, const double *poses, int multi);
 /* multi_margi (VS:1590-1679): OctoTree::margi (VM:1465-1598, mgsize = 1) on every root of the sliding map
- * using the factor store's refined eig/pcr_add, then drops roots with !isexist from the sliding map. */
-int vba_map_margi(vba_ctx *ctx, int win_count, const double *poses);
+ * using the factor store's refined eig/pcr_add, then drops roots with !isexist from the sliding map.
+ * jour is stamped on every sliding-map root (VS:1628). */
+int vba_map_margi(vba_ctx *ctx, int win_count, const double *poses, double jour);
 /* Ring-map rotation mp[i] = (mp[i] + mgsize) mod W (VS:2014-2019). */
 int vba_map_slide(vba_ctx *ctx, int mgsize);
 /* Destroys the map (system_reset / motion_init teardown, VS:650-661). */

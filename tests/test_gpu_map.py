@@ -1,0 +1,200 @@
+"""GPU parity tests (MI355X) for the device voxel map: K1 insert, K2 recut/plane-fit + factor extraction, K5
+marginalisation, against the CPU oracle's pointer-based octree (oracle/map_oracle.hpp) on the same seeded scans.
+Integer/structural state (keys, layers, octant paths, point counts, plane flags) must match exactly; floating sums are
+accumulated with f64 atomics in arrival order, so they are compared at 1e-11 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from voxel_slam_amd import synth as s
+    return s
+
+
+def _leaf_table(dump):
+    """key -> record, key = (kx, ky, kz, layer, path)"""
+    return {tuple(int(v) for v in r[:5]): r for r in dump}
+
+
+def _compare_leaves(gd, od, check_plane=True):
+    g, o = _leaf_table(gd), _leaf_table(od)
+    assert set(g) == set(o), "leaf sets differ: %d vs %d (sym diff %d)" % (len(g), len(o), len(set(g) ^ set(o)))
+    nplane = 0
+    for k, ro in o.items():
+        rg = g[k]
+        assert rg[5] == ro[5] and rg[6] == ro[6], (k, rg[5:7], ro[5:7])       # N_add, N_fix
+        assert rg[8] == ro[8], (k, "isexist", rg[8], ro[8])
+        scale = max(1.0, np.abs(ro[22:31]).max())
+        assert np.abs(rg[22:32] - ro[22:32]).max() < 1e-11 * scale, (k, "pcr_add")
+        if check_plane:
+            assert rg[7] == ro[7], (k, "is_plane", rg[10:13], ro[10:13])
+            if ro[7]:
+                nplane += 1
+                m2 = np.abs(ro[22:28]).max() / ro[31]
+                assert np.abs(rg[10:13] - ro[10:13]).max() < 1e-14 * max(m2, 1.0), (k, rg[10:13], ro[10:13])
+    return nplane
+
+
+def _opts(capi, wl, **kw):
+    o = capi.options_from_workload(wl)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _omap(oracle, wl, **kw):
+    return oracle.VoxelMap(wl.win_size, wl.voxel_size, wl.max_layer, wl.min_eigen_value, wl.plane_thre, wl.min_point, wl.max_points,
+                           kw.get("thread_num", 5))
+
+
+def _rand_var(n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, 0.01, (n, 3, 3))
+    return np.ascontiguousarray((A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)).reshape(n, 9))
+
+
+def test_key_quirk_on_device(capi, oracle):
+    """One point per voxel: the device key function must reproduce voxel_map.hpp:1907-1918 incl. negative integers."""
+    d = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "kat_key.npz"))
+    coords = d["coords"][np.abs(d["coords"]) < 1e5]
+    pts = np.stack([coords, -coords, 0.37 * coords], 1)
+    for vs in (0.3, 0.5, 1.0):
+        o = capi.default_options(); o.win_size = 4; o.voxel_size = vs
+        ctx = capi.Context(o)
+        ctx.cut_voxel(0, pts, np.concatenate([np.eye(3).ravel(), np.zeros(3)]))
+        got = {tuple(int(v) for v in r[:3]) for r in ctx.dump_leaves()}
+        want = {tuple(int(v) for v in oracle.map_key(vs, p)) for p in pts}
+        assert got == want
+
+
+@pytest.mark.parametrize("name,with_var", [("room20k_w4", False), ("room20k_w4", True), ("avia100k_w10", False)])
+def test_full_window_rebuild_parity(capi, oracle, synth, name, with_var):
+    """motion_init flow (voxelslam.cpp:664-703): cut_voxel for every scan of the window, then recut + tras_opt."""
+    wl = synth.CONFIGS[name]
+    s = synth.make_scans(wl)
+    W = wl.win_size
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    ctx = capi.Context(_opts(capi, wl))
+    om = _omap(oracle, wl)
+    for i in range(W):
+        var = _rand_var(len(s["points"][i]), i) if with_var else None
+        ctx.cut_voxel(i, s["points"][i], poses[i], var=var)
+        om.cut_voxel(i, s["points"][i], poses[i], var=var)
+    assert ctx.num_roots() == om.num_roots() and ctx.num_slide_roots() == om.num_slide_roots()
+    _compare_leaves(ctx.dump_leaves(), om.dump_leaves(), check_plane=False)
+
+    of = oracle.Factor(W)
+    om.recut(W, poses, of, multi=False)
+    ctx.recut(W, poses, multi=False)
+    nplane = _compare_leaves(ctx.dump_leaves(), om.dump_leaves())
+    assert nplane > 50
+    assert ctx.size() == of.size() and ctx.size() > 50
+    # the extracted factor stores are equivalent: same H, g, residual (summation order aside)
+    H, g, r = ctx.acc_evaluate2(poses)
+    H2, g2, r2 = of.acc_evaluate2(poses)
+    assert abs(r - r2) < 1e-11 * abs(r2)
+    assert np.abs(H - H2).max() < 1e-9 * np.abs(H2).max() and np.abs(g - g2).max() < 1e-9 * np.abs(g2).max()
+    # and the BA on top of them ends at the same poses
+    a = ctx.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
+    b = of.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-6      # bar: 1e-4 m / 1e-4 rad
+
+
+def test_incremental_local_mapping_parity(capi, oracle, synth):
+    """Steady-state loop of thd_odometry_localmapping (voxelslam.cpp:1916-2043): per scan cut_voxel_multi -> multi_recut ->
+    (window full) damping_iter -> multi_margi -> ring rotation, for more scans than the window holds."""
+    import dataclasses
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], win_size=4)
+    W = wl.win_size
+    nscan = 9
+    big = dataclasses.replace(wl, win_size=nscan)
+    s = synth.make_scans(big)      # nscan scans along the trajectory
+    ctx = capi.Context(_opts(capi, wl))
+    om = _omap(oracle, wl)
+    of = oracle.Factor(W)
+    x_g, x_o = [], []              # window poses on each side
+    win_count = 0
+    n_ba = 0
+    for k in range(nscan):
+        pose = synth.poses_flat(s["R0"][k:k + 1], s["p0"][k:k + 1])[0]
+        var = _rand_var(len(s["points"][k]), 100 + k)
+        x_g.append(pose.copy()); x_o.append(pose.copy())
+        win_count += 1
+        ctx.cut_voxel(win_count - 1, s["points"][k], x_g[-1], var=var, multi=True)
+        om.cut_voxel(win_count - 1, s["points"][k], x_o[-1], var=var, multi=True)
+        ctx.recut(win_count, np.array(x_g), multi=True)
+        om.recut(win_count, np.array(x_o), of, multi=True)
+        assert ctx.size() == of.size()
+        _compare_leaves(ctx.dump_leaves(), om.dump_leaves())
+        if win_count >= W:
+            a = ctx.lidar_ba_damping_iter(np.array(x_g), max_iter=3, thd_num=2)
+            b = of.lidar_ba_damping_iter(np.array(x_o), max_iter=3, thd_num=2)
+            assert np.abs(a["poses"] - b["poses"]).max() < 1e-6      # bar: 1e-4 m / 1e-4 rad
+            x_g = [p for p in a["poses"]]; x_o = [p for p in b["poses"]]
+            n_ba += 1
+            ctx.margi(win_count, np.array(x_g), jour=float(k))
+            om.margi(win_count, np.array(x_o), of)
+            assert ctx.num_slide_roots() == om.num_slide_roots()
+            gd, od = ctx.dump_leaves(), om.dump_leaves()
+            _compare_leaves(gd, od)
+            # refined plane parameters (plane.center / normal / radius written by plane_update, voxel_map.hpp:1344-1388)
+            g, o = _leaf_table(gd), _leaf_table(od)
+            npl = 0
+            for key, ro in o.items():
+                if ro[7] and np.abs(ro[35:38]).max() > 0:
+                    rg = g[key]
+                    assert np.abs(rg[32:35] - ro[32:35]).max() < 1e-9, (key, "center")
+                    assert abs(abs(np.dot(rg[35:38], ro[35:38])) - 1) < 1e-9, (key, "normal")
+                    assert abs(rg[38] - ro[38]) < 1e-6 * max(1e-3, abs(ro[38])), (key, "radius")
+                    npl += 1
+            assert npl > 20
+            ctx.slide(1); om.slide(1)
+            x_g = x_g[1:]; x_o = x_o[1:]
+            win_count -= 1
+    assert n_ba == nscan - W + 1
+
+
+def test_fixed_point_insertion_parity(capi, oracle, synth):
+    """cut_voxel(fix) (voxel_map.hpp:2108-2152) before and after window scans, then recut with fix_divide."""
+    wl = synth.CONFIGS["room20k_w4"]
+    s = synth.make_scans(wl)
+    W = wl.win_size
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    ctx = capi.Context(_opts(capi, wl))
+    om = _omap(oracle, wl)
+    fixed = (s["points"][0] @ s["R_gt"][0].T + s["p_gt"][0])[::3]
+    ctx.cut_voxel_fix(fixed, jour=1.5); om.cut_voxel_fix(fixed, jour=1.5)
+    assert ctx.num_roots() == om.num_roots() and ctx.num_slide_roots() == 0 == om.num_slide_roots()
+    for i in range(1, W):
+        ctx.cut_voxel(i, s["points"][i], poses[i]); om.cut_voxel(i, s["points"][i], poses[i])
+    of = oracle.Factor(W)
+    ctx.recut(W, poses, multi=False); om.recut(W, poses, of, multi=False)
+    _compare_leaves(ctx.dump_leaves(), om.dump_leaves())
+    more = (s["points"][1] @ s["R_gt"][1].T + s["p_gt"][1])[1::5]
+    ctx.cut_voxel_fix(more, jour=2.5); om.cut_voxel_fix(more, jour=2.5)
+    _compare_leaves(ctx.dump_leaves(), om.dump_leaves(), check_plane=False)
+    assert ctx.size() == of.size()
+
+
+def test_scan_dropped_when_fewer_voxels_than_threads(capi, oracle):
+    """cut_voxel_multi silently drops a scan that touches fewer voxels than thread_num (voxel_map.hpp:2044-2045)."""
+    o = capi.default_options(); o.win_size = 4; o.voxel_size = 1.0; o.thread_num = 5
+    ctx = capi.Context(o)
+    om = oracle.VoxelMap(4, 1.0, thread_num=5)
+    pts = np.random.default_rng(0).uniform(0.1, 0.9, (50, 3)) + np.array([[0, 0, 0]] * 25 + [[3, 0, 0]] * 25)
+    pose = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
+    ctx.cut_voxel(0, pts, pose, multi=True); om.cut_voxel(0, pts, pose, multi=True)
+    assert ctx.num_roots() == om.num_roots() == 2
+    gd, od = ctx.dump_leaves(), om.dump_leaves()
+    assert gd[:, 5].sum() == 0 == od[:, 5].sum()       # roots exist, but no point was accumulated
+    _compare_leaves(gd, od, check_plane=False)

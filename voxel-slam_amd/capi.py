@@ -248,9 +248,9 @@ class Context:
         poses = _c(poses)
         self._chk(self.lib.vba_map_recut(self.h, C.c_int(win_count), _p(poses), C.c_int(int(multi))))
 
-    def margi(self, win_count, poses):
+    def margi(self, win_count, poses, jour=0.0):
         poses = _c(poses)
-        self._chk(self.lib.vba_map_margi(self.h, C.c_int(win_count), _p(poses)))
+        self._chk(self.lib.vba_map_margi(self.h, C.c_int(win_count), _p(poses), C.c_double(jour)))
 
     def slide(self, mgsize=1):
         self._chk(self.lib.vba_map_slide(self.h, C.c_int(mgsize)))

@@ -1,9 +1,19 @@
-// Device voxel hash map + octree (K1 insert, K2 recut/plane fit, K5 marginalise).  PLACEHOLDER interface:
-// the full implementation follows in this round; until then every map entry reports "not implemented".
+// Device-resident voxel hash map + adaptive octree of Voxel-SLAM's local mapping (gfx950 / wave64):
+//   K1 insert       <-> cut_voxel / cut_voxel_multi VM:1896-2096, OctoTree::allocate/push VM:1204/1105, Bf_var VM:106,
+//                       cut_voxel(fix) VM:2108-2152, allocate_fix / push_fix_novar VM:1239/1168
+//   K2 recut        <-> OctoTree::recut VM:1396-1456 (plane_judge 1185, fix_divide 1270, subdivide 1307),
+//                       multi_recut VS:1682-1737, tras_opt VM:1605-1638 (writes the SoA factor store directly)
+//   K5 marginalise  <-> OctoTree::margi VM:1465-1598, plane_update VM:1344-1388, multi_margi VS:1590-1679
+// Design: explicit per-node state in SoA arrays, roots in an open-addressing hash table keyed by the
+// packed voxel key, children allocated as blocks of 8 when a leaf is subdivided, raw window points kept in a ring of
+// W scan slots with a per-point leaf assignment (the "points of leaf X, frame i" lists of the reference), fixed points
+// in an append-only pool with a per-point owner.  The tree is processed level-synchronously (<= max_layer+1 passes).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
 #include <string>
+#include <vector>
 #include "../../include/voxelba.h"
 #include "vba_kernels_factor.hpp"
 
@@ -18,22 +28,984 @@ __host__ __device__ inline uint64_t shard_bucket(int64_t kx, int64_t ky, int64_t
   return h & 0xFFFFull;
 }
 
+static constexpr unsigned long long KEY_EMPTY = ~0ull;
+static constexpr int KEY_BITS = 21, KEY_OFF = 1 << 20;
+
+__host__ __device__ inline unsigned long long pack_key(long long kx, long long ky, long long kz) {
+  return ((unsigned long long)(kx + KEY_OFF) << 42) | ((unsigned long long)(ky + KEY_OFF) << 21) | (unsigned long long)(kz + KEY_OFF);
+}
+__host__ __device__ inline void unpack_key(unsigned long long k, long long &kx, long long &ky, long long &kz) {
+  kx = (long long)((k >> 42) & 0x1FFFFF) - KEY_OFF; ky = (long long)((k >> 21) & 0x1FFFFF) - KEY_OFF; kz = (long long)(k & 0x1FFFFF) - KEY_OFF;
+}
+// The reference's key quirk VM:1907-1918: float narrowing, -1 if negative, truncation toward zero.
+__host__ __device__ inline long long key_axis(double pw, double voxel_size) {
+  float loc = (float)(pw / voxel_size);
+  if (loc < 0) loc -= 1.0f;
+  return (long long)loc;
+}
+
+enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_N };
+
+struct MapParams {
+  int W, max_layer, max_points, thread_num;
+  double voxel_size, min_eigen_value;
+  double plane_thre[4], min_point[4];
+  int mp[VBA_MAX_WIN];
+  int rank, n_ranks;
+};
+
+struct MapView {
+  // hash table of roots
+  unsigned long long *hkeys; int *hvals; unsigned int hmask;
+  // nodes
+  int cap;
+  unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
+  signed char *nlayer; signed char *nstate;
+  unsigned char *f_exist, *f_sw, *f_plane, *f_touched; int *f_slide;
+  float *nql; double *ncenter; double *njour;
+  double *nadd, *nfix, *ncov, *neval, *nevec, *nplane, *nlc;
+  // scan ring
+  int max_pts;
+  double *px;   // [3][W][max_pts]
+  double *pvar; // [9][W][max_pts]
+  int *pnode;   // [W][max_pts]
+  int *phash;   // [max_pts] temp
+  int *newslots;  // [max_pts] temp
+  // fixed-point pool
+  int cap_fix;
+  double *fx;   // [3][cap_fix]
+  double *fvar; // [9][cap_fix]
+  int *fnode;
+  int *cnt;     // counters [CNT_N]
+  double *poses;  // [W][12]
+};
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ void atomic_cluster_add(double *base, size_t fstride, double x, double y, double z) {
+  unsafeAtomicAdd(base + 0 * fstride, x * x); unsafeAtomicAdd(base + 1 * fstride, x * y); unsafeAtomicAdd(base + 2 * fstride, x * z);
+  unsafeAtomicAdd(base + 3 * fstride, y * y); unsafeAtomicAdd(base + 4 * fstride, y * z); unsafeAtomicAdd(base + 5 * fstride, z * z);
+  unsafeAtomicAdd(base + 6 * fstride, x); unsafeAtomicAdd(base + 7 * fstride, y); unsafeAtomicAdd(base + 8 * fstride, z);
+  unsafeAtomicAdd(base + 9 * fstride, 1.0);
+}
+
+// Bf_var (VM:106-121): 9x9 symmetric block [Bi var Bi^T, Bi var; (Bi var)^T, var]; upper triangle (45) added atomically.
+__device__ __forceinline__ void atomic_bfvar_add(double *base, size_t fstride, const double *var, double x, double y, double z) {
+  const double Bi[6][3] = {{2 * x, 0, 0}, {y, x, 0}, {z, 0, x}, {0, 2 * y, 0}, {0, z, y}, {0, 0, 2 * z}};
+  double Bu[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) Bu[r][c] = Bi[r][0] * var[0 * 3 + c] + Bi[r][1] * var[1 * 3 + c] + Bi[r][2] * var[2 * 3 + c];
+  int idx = 0;
+#pragma unroll
+  for (int r = 0; r < 9; r++)
+#pragma unroll
+    for (int c = r; c < 9; c++) {
+      double val;
+      if (r < 6 && c < 6) val = Bu[r][0] * Bi[c][0] + Bu[r][1] * Bi[c][1] + Bu[r][2] * Bi[c][2];
+      else if (r < 6) val = Bu[r][c - 6];
+      else val = var[(r - 6) * 3 + (c - 6)];
+      if (val != 0.0) unsafeAtomicAdd(base + (size_t)idx * fstride, val);
+      idx++;
+    }
+}
+
+__device__ __forceinline__ int octant_of(const MapView &m, int node, double x, double y, double z) {
+  const size_t cp = (size_t)m.cap;
+  const int ox = x > m.ncenter[node] ? 1 : 0, oy = y > m.ncenter[cp + node] ? 1 : 0, oz = z > m.ncenter[2 * cp + node] ? 1 : 0;
+  return 4 * ox + 2 * oy + oz;   // VM:1214-1219
+}
+
+__device__ __forceinline__ void init_node(const MapView &m, int id, unsigned long long key, int root, int parent, int layer, int path,
+                                          double cx, double cy, double cz, float ql) {
+  const size_t cp = (size_t)m.cap;
+  m.nkey[id] = key; m.nroot[id] = root; m.nparent[id] = parent; m.nchild[id] = -1; m.npath[id] = path; m.nopt[id] = -1; m.nlast[id] = 0;
+  m.nstamp[id] = 0; m.nsplit[id] = 0; m.ntake[id] = 0; m.nclear[id] = 0; m.ndead[id] = 0;
+  m.nlayer[id] = (signed char)layer; m.nstate[id] = 0;
+  m.f_exist[id] = 0; m.f_sw[id] = 0; m.f_plane[id] = 0; m.f_touched[id] = 0; m.f_slide[id] = 0;
+  m.nql[id] = ql; m.ncenter[id] = cx; m.ncenter[cp + id] = cy; m.ncenter[2 * cp + id] = cz; m.njour[id] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------ K1: insert
+// Phase 1: world transform, key, find-or-claim the hash slot of the root voxel.
+__global__ void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
+  double x, y, z;
+  if (world_given) {  // fixed points arrive in world coordinates, staged in the pool tail (see map_cut_voxel_fix)
+    x = m.fx[(size_t)0 * m.cap_fix + slot + p]; y = m.fx[(size_t)1 * m.cap_fix + slot + p]; z = m.fx[(size_t)2 * m.cap_fix + slot + p];
+  } else {
+    const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+    const double *R = m.poses;  // the scan pose is staged at poses[0..12)
+    x = R[0] * bx + R[1] * by + R[2] * bz + R[9]; y = R[3] * bx + R[4] * by + R[5] * bz + R[10]; z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
+  }
+  const long long kx = key_axis(x, P.voxel_size), ky = key_axis(y, P.voxel_size), kz = key_axis(z, P.voxel_size);
+  m.phash[p] = -1;
+  if (kx < -KEY_OFF || kx >= KEY_OFF || ky < -KEY_OFF || ky >= KEY_OFF || kz < -KEY_OFF || kz >= KEY_OFF) { atomicAdd(&m.cnt[CNT_BADKEY], 1); return; }
+  if (P.n_ranks > 1 && (int)((shard_bucket(kx, ky, kz) * (uint64_t)P.n_ranks) >> 16) != P.rank) return;  // not this rank's bucket range
+  const unsigned long long key = pack_key(kx, ky, kz);
+  unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & m.hmask;
+  for (unsigned int probe = 0; probe <= m.hmask; probe++) {
+    unsigned long long cur = m.hkeys[h];
+    if (cur == key) break;
+    if (cur == KEY_EMPTY) {
+      const unsigned long long prev = atomicCAS(&m.hkeys[h], KEY_EMPTY, key);
+      if (prev == KEY_EMPTY) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = (int)h; break; }
+      if (prev == key) break;
+    }
+    h = (h + 1) & m.hmask;
+  }
+  m.phash[p] = (int)h;
+}
+
+// Phase 2: one thread per newly claimed hash slot creates the root node (VM:1935-1946).
+__global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.cnt[CNT_NEWSLOTS]) return;
+  const int h = m.newslots[i];
+  const int id = atomicAdd(&m.cnt[CNT_NODES], 1);
+  if (id >= m.cap) { m.cnt[CNT_OVERFLOW] = 1; return; }
+  long long kx, ky, kz;
+  const unsigned long long key = m.hkeys[h];
+  unpack_key(key, kx, ky, kz);
+  init_node(m, id, key, id, -1, 0, 0, (0.5 + kx) * P.voxel_size, (0.5 + ky) * P.voxel_size, (0.5 + kz) * P.voxel_size, (float)(P.voxel_size / 4.0));
+  if (is_fix) m.njour[id] = jour;   // VM:2147
+  m.hvals[h] = id;
+  atomicAdd(&m.cnt[CNT_ROOTS], 1);
+}
+
+// Phase 3 (window scans only): mark roots (isexist, sliding map membership, per-scan touch count) VM:1997-2001, 2016-2017.
+__global__ void k_ins_touch(MapView m, int n, int stamp) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int h = m.phash[p];
+  if (h < 0) return;
+  const int root = m.hvals[h];
+  if (root < 0) return;
+  m.f_exist[root] = 1;
+  if (m.f_slide[root] == 0 && atomicExch(&m.f_slide[root], 1) == 0) atomicAdd(&m.cnt[CNT_SLIDE], 1);
+  if (m.nstamp[root] != stamp && atomicExch(&m.nstamp[root], stamp) != stamp) atomicAdd(&m.cnt[CNT_TOUCH], 1);
+}
+
+// Phase 4: descend to the leaf and accumulate (OctoTree::allocate VM:1204 -> push VM:1105-1143).
+__global__ void k_ins_accum(MapView m, MapParams P, int slot, int n, int multi, int has_var) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
+  int *pn = m.pnode + (size_t)slot * mpz + p;
+  *pn = -1;
+  if (multi && m.cnt[CNT_TOUCH] < P.thread_num) return;   // VM:2044-2045: the scan is dropped
+  const int h = m.phash[p];
+  if (h < 0) return;
+  int node = m.hvals[h];
+  if (node < 0) return;
+  const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+  const double *R = m.poses;
+  const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
+  while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+  atomic_cluster_add(m.nlc + (size_t)slot * cp + node, W * cp, bx, by, bz);   // sw->pcrs_local[mord].push(pv.pnt)  VM:1134
+  atomic_cluster_add(m.nadd + node, cp, x, y, z);                             // pcr_add.push(pw)              VM:1136
+  if (has_var) {
+    double var[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+    atomic_bfvar_add(m.ncov + node, cp, var, x, y, z);                        // cov_add += Bf_var(pv, pw)      VM:1138-1140
+  }
+  m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1;
+  *pn = node;
+}
+
+// Fixed points (VM:2108-2152): new root -> push_fix_novar on the root; else allocate_fix (descend while layer < max_layer).
+__global__ void k_fix_accum(MapView m, MapParams P, int base, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
+  const int q = base + p;
+  m.fnode[q] = -1;
+  const int h = m.phash[p];
+  if (h < 0) return;
+  int node = m.hvals[h];
+  if (node < 0) return;
+  const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
+  while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+  atomic_cluster_add(m.nfix + node, cp, x, y, z);   // pcr_fix.push  VM:1174
+  atomic_cluster_add(m.nadd + node, cp, x, y, z);   // pcr_add.push  VM:1176
+  m.f_touched[node] = 1;
+  if (m.nlayer[node] < P.max_layer) m.fnode[q] = node;  // point_fix.push_back only below max_layer (VM:1171-1172)
+}
+
+// ------------------------------------------------------------------------------------------------ K2: recut
+__device__ __forceinline__ bool in_scope(const MapView &m, const MapParams &P, int node, int multi) {
+  if (!multi) return true;
+  return m.f_slide[m.nroot[node]] != 0;
+}
+
+// One thread per node of layer L: leaf logic of OctoTree::recut VM:1399-1450.
+__global__ void k_recut_leaf(MapView m, MapParams P, int L, int multi, int epoch) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nlayer[id] != L || m.nstate[id] != 0) return;
+  if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;   // VS:1693-1694
+  if (!in_scope(m, P, id, multi)) return;
+  const size_t cp = (size_t)m.cap;
+  m.nopt[id] = -1;
+  const double N = m.nadd[9 * cp + id];
+  if (N <= P.min_point[L]) { m.f_plane[id] = 0; return; }   // VM:1406-1410
+  if (!m.f_exist[id] || !m.f_sw[id]) return;                // VM:1412-1413
+  const double b0 = m.nadd[6 * cp + id] / N, b1 = m.nadd[7 * cp + id] / N, b2 = m.nadd[8 * cp + id] / N;
+  double w0, w1, w2, V[9];
+  eig3_sym_dev(m.nadd[0 * cp + id] / N - b0 * b0, m.nadd[1 * cp + id] / N - b1 * b0, m.nadd[2 * cp + id] / N - b2 * b0,
+               m.nadd[3 * cp + id] / N - b1 * b1, m.nadd[4 * cp + id] / N - b2 * b1, m.nadd[5 * cp + id] / N - b2 * b2, w0, w1, w2, V);
+  m.neval[id] = w0; m.neval[cp + id] = w1; m.neval[2 * cp + id] = w2;
+#pragma unroll
+  for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = V[k];
+  const bool plane = (w0 < P.min_eigen_value) && ((w0 / w2) < P.plane_thre[L]);   // plane_judge VM:1194
+  m.f_plane[id] = plane ? 1 : 0;
+  if (plane || L >= P.max_layer) return;
+  // subdivide: children are created as a block of 8 (untouched octants stay empty leaves, which every traversal skips)
+  const int base = atomicAdd(&m.cnt[CNT_NODES], 8);
+  if (base + 8 > m.cap) { m.cnt[CNT_OVERFLOW] = 1; return; }
+  const double cx = m.ncenter[id], cy = m.ncenter[cp + id], cz = m.ncenter[2 * cp + id];
+  const float ql = m.nql[id];
+  for (int o = 0; o < 8; o++) {
+    const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
+    // VM:1227-1231: double + int * float
+    init_node(m, base + o, m.nkey[id], m.nroot[id], id, L + 1, (L == 0 ? o : m.npath[id] * 8 + o), cx + (2 * ox - 1) * ql, cy + (2 * oy - 1) * ql,
+              cz + (2 * oz - 1) * ql, ql / 2);
+  }
+  m.nchild[id] = base;
+  m.nsplit[id] = epoch;    // the point kernels of this pass move this leaf's points to the children
+  m.nstate[id] = 1;        // VM:1449
+  m.f_sw[id] = 0;          // sw->clear(); sws.push_back(sw); sw = nullptr  VM:1445-1447
+  for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
+}
+
+// Window points of split leaves -> children, keyed with the CURRENT poses (subdivide VM:1307-1338 + push).
+__global__ void k_recut_points(MapView m, MapParams P, int win_count, int epoch, int has_var) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int fi = blockIdx.y;   // frame
+  if (p >= m.max_pts || fi >= win_count) return;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
+  const int slot = P.mp[fi];
+  int *pn = m.pnode + (size_t)slot * mpz + p;
+  const int node = *pn;
+  if (node < 0 || m.nsplit[node] != epoch) return;
+  const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+  const double *R = m.poses + 12 * fi;
+  const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
+  const int child = m.nchild[node] + octant_of(m, node, x, y, z);
+  atomic_cluster_add(m.nlc + (size_t)slot * cp + child, W * cp, bx, by, bz);
+  atomic_cluster_add(m.nadd + child, cp, x, y, z);
+  if (has_var) {
+    double var[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+    atomic_bfvar_add(m.ncov + child, cp, var, x, y, z);
+  }
+  m.f_sw[child] = 1; m.f_exist[child] = 1; m.f_touched[child] = 1;
+  *pn = child;
+}
+
+// Fixed points of split leaves -> children (fix_divide VM:1270-1299 + push_fix VM:1149-1162).
+__global__ void k_recut_fixpts(MapView m, MapParams P, int epoch, int child_layer) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = m.cnt[CNT_FIX] < m.cap_fix ? m.cnt[CNT_FIX] : m.cap_fix;
+  if (q >= nf) return;
+  const int node = m.fnode[q];
+  if (node < 0 || m.nsplit[node] != epoch) return;
+  const size_t cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
+  const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
+  const int child = m.nchild[node] + octant_of(m, node, x, y, z);
+  atomic_cluster_add(m.nfix + child, cp, x, y, z);
+  atomic_cluster_add(m.nadd + child, cp, x, y, z);
+  double var[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)k * cf + q];
+  atomic_bfvar_add(m.ncov + child, cp, var, x, y, z);
+  m.f_touched[child] = 1;
+  m.fnode[q] = (child_layer < P.max_layer) ? child : -1;   // VM:1152-1153
+}
+
+// tras_opt VM:1605-1638, pass 1: assign factor indices.
+__global__ void k_extract_count(MapView m, MapParams P, int multi) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nstate[id] != 0) return;
+  if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;
+  if (!in_scope(m, P, id, multi)) return;
+  if (!(m.f_exist[id] && m.f_plane[id] && m.f_sw[id])) return;
+  const size_t cp = (size_t)m.cap;
+  if (m.neval[id] / m.neval[cp + id] > 0.12) return;   // VM:1615
+  m.nopt[id] = atomicAdd(&m.cnt[CNT_FACTORS], 1);        // opt_state  VM:1626
+}
+// pass 2: write the SoA factor store (push_voxel VM:139-147), frames in ring order pcrs[i] = pcrs_local[mp[i]] VM:1623-1624.
+__global__ void k_extract_write(MapView m, MapParams P, FactorView f, int multi) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nstate[id] != 0 || !in_scope(m, P, id, multi)) return;
+  if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;
+  const int a = m.nopt[id];
+  if (a < 0 || a >= f.vs) return;
+  const size_t cp = (size_t)m.cap, vs = (size_t)f.vs, W = (size_t)P.W;
+  for (int i = 0; i < P.W; i++) {
+    const int slot = P.mp[i];
+    for (int k = 0; k < 10; k++) f.cl[((size_t)k * W + i) * vs + a] = m.nlc[((size_t)k * W + slot) * cp + id];
+  }
+  for (int k = 0; k < 10; k++) { f.fix[(size_t)k * vs + a] = m.nfix[(size_t)k * cp + id]; f.pcr[(size_t)k * vs + a] = m.nadd[(size_t)k * cp + id]; }
+  f.coe[a] = 1.0;   // VM:1619
+  for (int k = 0; k < 3; k++) f.eigval[(size_t)k * vs + a] = m.neval[(size_t)k * cp + id];
+  for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + a] = m.nevec[(size_t)k * cp + id];
+}
+
+// ------------------------------------------------------------------------------------------------ K5: marginalise
+__device__ __forceinline__ void cluster_transform_dev(const double *c /*10*/, const double *R /*12*/, double *o /*10*/) {
+  const double n = c[9], tx = R[9], ty = R[10], tz = R[11];
+  const double rv0 = R[0] * c[6] + R[1] * c[7] + R[2] * c[8], rv1 = R[3] * c[6] + R[4] * c[7] + R[5] * c[8], rv2 = R[6] * c[6] + R[7] * c[7] + R[8] * c[8];
+  const double m00 = R[0] * c[0] + R[1] * c[1] + R[2] * c[2], m01 = R[0] * c[1] + R[1] * c[3] + R[2] * c[4], m02 = R[0] * c[2] + R[1] * c[4] + R[2] * c[5];
+  const double m10 = R[3] * c[0] + R[4] * c[1] + R[5] * c[2], m11 = R[3] * c[1] + R[4] * c[3] + R[5] * c[4], m12 = R[3] * c[2] + R[4] * c[4] + R[5] * c[5];
+  const double m20 = R[6] * c[0] + R[7] * c[1] + R[8] * c[2], m21 = R[6] * c[1] + R[7] * c[3] + R[8] * c[4], m22 = R[6] * c[2] + R[7] * c[4] + R[8] * c[5];
+  o[0] = (m00 * R[0] + m01 * R[1] + m02 * R[2]) + 2.0 * rv0 * tx + n * tx * tx;
+  o[1] = (m10 * R[0] + m11 * R[1] + m12 * R[2]) + (rv1 * tx + rv0 * ty) + n * ty * tx;
+  o[2] = (m20 * R[0] + m21 * R[1] + m22 * R[2]) + (rv2 * tx + rv0 * tz) + n * tz * tx;
+  o[3] = (m10 * R[3] + m11 * R[4] + m12 * R[5]) + 2.0 * rv1 * ty + n * ty * ty;
+  o[4] = (m20 * R[3] + m21 * R[4] + m22 * R[5]) + (rv2 * ty + rv1 * tz) + n * tz * ty;
+  o[5] = (m20 * R[6] + m21 * R[7] + m22 * R[8]) + 2.0 * rv2 * tz + n * tz * tz;
+  o[6] = rv0 + n * tx; o[7] = rv1 + n * ty; o[8] = rv2 + n * tz; o[9] = n;
+}
+
+// plane_update VM:1344-1388.  nplane layout: center(3) normal(3) radius(1) plane_var(36 row-major)
+__device__ void plane_update_dev(const MapView &m, int id, const double *add /*10*/, const double *ev /*3*/, const double *U /*9*/) {
+  const size_t cp = (size_t)m.cap;
+  const double nv = 1.0 / add[9];
+  const double c[3] = {add[6] * nv, add[7] * nv, add[8] * nv};
+  const double u[3][3] = {{U[0], U[3], U[6]}, {U[1], U[4], U[7]}, {U[2], U[5], U[8]}};   // u[k] = column k
+  double uc[3][9];
+  for (int r = 0; r < 3; r++) for (int k = 0; k < 9; k++) uc[r][k] = 0.0;
+  for (int k = 1; k < 3; k++) {
+    // ukl = u[k] u[0]^T ; fkl(0..5) from its symmetric part, fkl(6..8) = -(u[k].c u[0] + u[0].c u[k])
+    double fkl[9];
+    const double *a = u[k], *b = u[0];
+    fkl[0] = a[0] * b[0]; fkl[1] = a[1] * b[0] + a[0] * b[1]; fkl[2] = a[2] * b[0] + a[0] * b[2];
+    fkl[3] = a[1] * b[1]; fkl[4] = a[1] * b[2] + a[2] * b[1]; fkl[5] = a[2] * b[2];
+    const double ac = a[0] * c[0] + a[1] * c[1] + a[2] * c[2], bc = b[0] * c[0] + b[1] * c[1] + b[2] * c[2];
+    for (int j = 0; j < 3; j++) fkl[6 + j] = -(ac * b[j] + bc * a[j]);
+    const double s = nv / (ev[0] - ev[k]);
+    for (int r = 0; r < 3; r++) for (int j = 0; j < 9; j++) uc[r][j] += s * a[r] * fkl[j];
+  }
+  // Jc = u_c * cov_add (cov_add symmetric, upper triangle stored)
+  double Jc[3][9];
+  for (int r = 0; r < 3; r++)
+    for (int j = 0; j < 9; j++) {
+      double s = 0;
+      for (int k = 0; k < 9; k++) {
+        const int rr = k < j ? k : j, cc = k < j ? j : k;
+        s += uc[r][k] * m.ncov[(size_t)(rr * 9 - rr * (rr - 1) / 2 + (cc - rr)) * cp + id];
+      }
+      Jc[r][j] = s;
+    }
+  double *pl = m.nplane;
+  for (int j = 0; j < 3; j++) { pl[(size_t)j * cp + id] = c[j]; pl[(size_t)(3 + j) * cp + id] = u[0][j]; }
+  pl[(size_t)6 * cp + id] = (double)(float)ev[2];   // float radius (VM:89, VM:1387)
+  double pv[36];
+  for (int r = 0; r < 3; r++)
+    for (int cidx = 0; cidx < 3; cidx++) {
+      double s = 0;
+      for (int k = 0; k < 9; k++) s += Jc[r][k] * uc[cidx][k];
+      pv[r * 6 + cidx] = s;                                // Jc * u_c^T
+      const double jn = nv * Jc[r][6 + cidx];
+      pv[r * 6 + 3 + cidx] = jn; pv[(3 + cidx) * 6 + r] = jn;   // Jc_N and its transpose
+      const int rr = 6 + (r < cidx ? r : cidx), cc = 6 + (r < cidx ? cidx : r);
+      pv[(3 + r) * 6 + 3 + cidx] = nv * nv * m.ncov[(size_t)(rr * 9 - rr * (rr - 1) / 2 + (cc - rr)) * cp + id];
+    }
+  for (int k = 0; k < 36; k++) pl[(size_t)(7 + k) * cp + id] = pv[k];
+}
+
+// One thread per leaf: OctoTree::margi leaf branch VM:1468-1584 with mgsize = 1.
+__global__ void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int win_count, int epoch) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nstate[id] != 0) return;
+  if (m.cnt[CNT_SLIDE] < P.thread_num) return;              // VS:1616-1617
+  if (m.f_slide[m.nroot[id]] == 0) return;
+  if (!m.f_exist[id] || !m.f_sw[id]) return;                // VM:1471-1472
+  const size_t cp = (size_t)m.cap, W = (size_t)P.W, vs = (size_t)f.vs;
+  double add[10], fix[10], pw0[10], ev[3], U[9], lc[10];
+  for (int k = 0; k < 10; k++) fix[k] = m.nfix[(size_t)k * cp + id];
+  for (int k = 0; k < 3; k++) ev[k] = m.neval[(size_t)k * cp + id];
+  for (int k = 0; k < 9; k++) U[k] = m.nevec[(size_t)k * cp + id];
+  for (int k = 0; k < 10; k++) pw0[k] = 0.0;
+  const int opt = m.nopt[id];
+  if (opt >= nfac) { m.cnt[CNT_OVERFLOW] = 2; return; }     // VM:1488-1492 "Error: opt_state"
+  const int slot0 = P.mp[0];
+  if (opt >= 0) {                                           // VM:1495-1509
+    for (int k = 0; k < 10; k++) add[k] = f.pcr[(size_t)k * vs + opt];
+    for (int k = 0; k < 3; k++) ev[k] = f.eigval[(size_t)k * vs + opt];
+    for (int k = 0; k < 9; k++) U[k] = f.eigvec[(size_t)k * vs + opt];
+    m.nopt[id] = -1;
+    for (int k = 0; k < 10; k++) lc[k] = m.nlc[((size_t)k * W + slot0) * cp + id];
+    if (lc[9] != 0.0) cluster_transform_dev(lc, m.poses, pw0);
+  } else {                                                  // VM:1510-1529
+    for (int k = 0; k < 10; k++) add[k] = fix[k];
+    for (int i = 0; i < win_count; i++) {
+      const int slot = P.mp[i];
+      for (int k = 0; k < 10; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
+      if (lc[9] != 0.0) {
+        double t[10];
+        cluster_transform_dev(lc, m.poses + 12 * i, t);
+        for (int k = 0; k < 10; k++) add[k] += t[k];
+        if (i == 0) for (int k = 0; k < 10; k++) pw0[k] = t[k];
+      }
+    }
+    if (m.f_plane[id]) {
+      const double N = add[9], b0 = add[6] / N, b1 = add[7] / N, b2 = add[8] / N;
+      eig3_sym_dev(add[0] / N - b0 * b0, add[1] / N - b1 * b0, add[2] / N - b2 * b0, add[3] / N - b1 * b1, add[4] / N - b2 * b1, add[5] / N - b2 * b2,
+                   ev[0], ev[1], ev[2], U);
+    }
+  }
+  for (int k = 0; k < 3; k++) m.neval[(size_t)k * cp + id] = ev[k];
+  for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = U[k];
+  if (fix[9] < P.max_points && m.f_plane[id]) {             // VM:1532-1538
+    const int last = m.nlast[id];
+    if ((int)add[9] - last >= 5 || last <= 10) { plane_update_dev(m, id, add, ev, U); m.nlast[id] = (int)add[9]; }
+  }
+  if (fix[9] < P.max_points) {                              // VM:1541-1555
+    if (pw0[9] != 0.0) {
+      for (int k = 0; k < 10; k++) fix[k] += pw0[k];
+      if (m.nlayer[id] < P.max_layer) m.ntake[id] = epoch;  // its frame-0 points move to the fixed pool (k_margi_points)
+    }
+  } else {                                                  // VM:1556-1566
+    if (pw0[9] != 0.0) for (int k = 0; k < 10; k++) add[k] -= pw0[k];
+    m.nclear[id] = epoch;                                   // PVec().swap(point_fix)
+  }
+  for (int k = 0; k < 10; k++) { m.nadd[(size_t)k * cp + id] = add[k]; m.nfix[(size_t)k * cp + id] = fix[k]; }
+  for (int k = 0; k < 10; k++) m.nlc[((size_t)k * W + slot0) * cp + id] = 0.0;   // VM:1569-1574
+  m.f_exist[id] = (fix[9] >= add[9]) ? 0 : 1;               // VM:1577-1580
+}
+
+// Frame-0 points of leaves that still collect fixed points -> pool, in world coordinates (VM:1549-1553); slot cleared.
+__global__ void k_margi_points(MapView m, MapParams P, int epoch, int has_var) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m.max_pts) return;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cf = (size_t)m.cap_fix;
+  const int slot = P.mp[0];
+  int *pn = m.pnode + (size_t)slot * mpz + p;
+  const int node = *pn;
+  *pn = -1;
+  if (node < 0 || m.ntake[node] != epoch) return;
+  const int q = atomicAdd(&m.cnt[CNT_FIX], 1);
+  if (q >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; return; }
+  const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+  const double *R = m.poses;
+  m.fx[q] = R[0] * bx + R[1] * by + R[2] * bz + R[9]; m.fx[cf + q] = R[3] * bx + R[4] * by + R[5] * bz + R[10]; m.fx[2 * cf + q] = R[6] * bx + R[7] * by + R[8] * bz + R[11];
+  for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.pvar[((size_t)k * W + slot) * mpz + p] : 0.0;
+  m.fnode[q] = node;
+}
+__global__ void k_margi_fixclear(MapView m, int epoch) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = m.cnt[CNT_FIX] < m.cap_fix ? m.cnt[CNT_FIX] : m.cap_fix;
+  if (q >= nf) return;
+  const int node = m.fnode[q];
+  if (node >= 0 && m.nclear[node] == epoch) m.fnode[q] = -1;
+}
+// Internal nodes, bottom-up: isexist = OR(children)  VM:1585-1597
+__global__ void k_margi_up(MapView m, MapParams P, int L) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nlayer[id] != L || m.nstate[id] != 1) return;
+  if (m.cnt[CNT_SLIDE] < P.thread_num || m.f_slide[m.nroot[id]] == 0) return;
+  unsigned char e = 0;
+  const int base = m.nchild[id];
+  for (int o = 0; o < 8; o++) e |= m.f_exist[base + o];
+  m.f_exist[id] = e;
+}
+// Roots: jour stamp (VS:1628); roots with !isexist leave the sliding map (VS:1665-1674)
+__global__ void k_margi_roots(MapView m, MapParams P, double jour, int epoch, int n_slide_before) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nlayer[id] != 0 || m.f_slide[id] == 0) return;
+  if (n_slide_before < P.thread_num) return;
+  m.njour[id] = jour;
+  if (!m.f_exist[id]) { m.f_slide[id] = 0; atomicSub(&m.cnt[CNT_SLIDE], 1); m.ndead[id] = epoch; }
+}
+// clear_slwd (VM:1856-1880) over the subtrees of the removed roots
+__global__ void k_margi_clear_nodes(MapView m, MapParams P, int epoch) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.ndead[m.nroot[id]] != epoch || !m.f_sw[id]) return;
+  const size_t cp = (size_t)m.cap;
+  for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
+  m.f_sw[id] = 0;
+}
+__global__ void k_margi_clear_points(MapView m, MapParams P, int epoch) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = blockIdx.y;
+  if (p >= m.max_pts) return;
+  int *pn = m.pnode + (size_t)slot * m.max_pts + p;
+  const int node = *pn;
+  if (node >= 0 && m.ndead[m.nroot[node]] == epoch) *pn = -1;
+}
+
+// ------------------------------------------------------------------------------------------------ dumps
+__global__ void k_dump_leaves(MapView m, double *out, int max_leaves) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nstate[id] != 0) return;
+  if (m.nlayer[id] > 0 && !m.f_touched[id]) return;   // never-touched octants do not exist in the reference tree
+  const int i = atomicAdd(&m.cnt[CNT_LEAVES], 1);
+  if (i >= max_leaves) return;
+  const size_t cp = (size_t)m.cap;
+  double *o = out + (size_t)i * 39;
+  long long kx, ky, kz;
+  unpack_key(m.nkey[id], kx, ky, kz);
+  o[0] = (double)kx; o[1] = (double)ky; o[2] = (double)kz; o[3] = m.nlayer[id]; o[4] = m.npath[id];
+  o[5] = m.nadd[9 * cp + id]; o[6] = m.nfix[9 * cp + id]; o[7] = m.f_plane[id]; o[8] = m.f_exist[id]; o[9] = m.nopt[id];
+  for (int k = 0; k < 3; k++) o[10 + k] = m.neval[(size_t)k * cp + id];
+  for (int k = 0; k < 9; k++) o[13 + k] = m.nevec[(size_t)k * cp + id];
+  for (int k = 0; k < 10; k++) o[22 + k] = m.nadd[(size_t)k * cp + id];
+  for (int k = 0; k < 7; k++) o[32 + k] = m.nplane[(size_t)k * cp + id];
+}
+
+__global__ void k_fill_u64(unsigned long long *p, unsigned long long v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_rehash(const unsigned long long *okeys, const int *ovals, unsigned int omask, unsigned long long *nkeys, int *nvals, unsigned int nmask) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > omask) return;
+  const unsigned long long key = okeys[i];
+  if (key == KEY_EMPTY) return;
+  unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & nmask;
+  while (true) {
+    if (atomicCAS(&nkeys[h], KEY_EMPTY, key) == KEY_EMPTY) { nvals[h] = ovals[i]; return; }
+    h = (h + 1) & nmask;
+  }
+}
+// AoS host layout [n][3] / [n][9] -> the scan slot's SoA arrays
+__global__ void k_scan_to_soa(MapView m, int W, int slot, int n, const double *pts, const double *var) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts;
+  for (int k = 0; k < 3; k++) m.px[((size_t)k * W + slot) * mpz + p] = pts[(size_t)p * 3 + k];
+  if (var) for (int k = 0; k < 9; k++) m.pvar[((size_t)k * W + slot) * mpz + p] = var[(size_t)p * 9 + k];
+}
+__global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t cf = (size_t)m.cap_fix;
+  for (int k = 0; k < 3; k++) m.fx[(size_t)k * cf + base + p] = pts[(size_t)p * 3 + k];
+  for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + base + p] = 0.0;   // push_fix_novar: no covariance
+}
+
+// ================================================================================================ host side
+struct DevArr {  // a [rows][cap] device array that can grow its cap keeping [rows][used]
+  void **slot; size_t elem, rows;
+};
+
 struct MapStore {
   vba_options opt;
   int rank = 0, n_ranks = 1;
+  MapView v{};
+  bool allocated = false;
+  bool have_var = false;
+  int mp[VBA_MAX_WIN];
+  int npts[VBA_MAX_WIN];
+  int epoch = 1, stamp = 1;
+  unsigned int hcap = 0;
+  int *h_cnt = nullptr;    // pinned
+  void *d_stage = nullptr; size_t stage_bytes = 0;
 };
 
-inline void map_init(MapStore &m, const vba_options &o) { m.opt = o; }
-inline void map_free(MapStore &) {}
-inline int map_ni(std::string &err) { err = "voxel map level not implemented yet"; return VBA_ERR_BAD_ARG; }
-inline int map_cut_voxel(MapStore &, hipStream_t, int, int, const double *, const double *, const double *, bool, std::string &e) { return map_ni(e); }
-inline int map_cut_voxel_fix(MapStore &, hipStream_t, int, const double *, double, std::string &e) { return map_ni(e); }
-inline int map_recut(MapStore &, hipStream_t, int, const double *, bool, std::string &e, int *) { return map_ni(e); }
-inline int map_extract_factors(MapStore &, hipStream_t, FactorView, std::string &e, int *) { return map_ni(e); }
-inline int map_margi(MapStore &, hipStream_t, int, const double *, FactorView, int, std::string &e) { return map_ni(e); }
-inline int map_slide(MapStore &, int) { return VBA_ERR_BAD_ARG; }
-inline int map_reset(MapStore &, hipStream_t, std::string &e) { return map_ni(e); }
-inline int map_num_roots(MapStore &, hipStream_t, bool) { return 0; }
-inline int map_dump_leaves(MapStore &, hipStream_t, double *, int, std::string &) { return 0; }
+inline void map_init(MapStore &s, const vba_options &o) {
+  s.opt = o;
+  for (int i = 0; i < VBA_MAX_WIN; i++) { s.mp[i] = i; s.npts[i] = 0; }   // VS:3158-3160
+}
+
+#define MAPCHK(expr)                                                                 \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(_e); return VBA_ERR_HIP; } \
+  } while (0)
+
+inline MapParams map_params(const MapStore &s) {
+  MapParams P;
+  P.W = s.opt.win_size; P.max_layer = s.opt.max_layer; P.max_points = s.opt.max_points; P.thread_num = s.opt.thread_num;
+  P.voxel_size = s.opt.voxel_size; P.min_eigen_value = s.opt.min_eigen_value;
+  for (int i = 0; i < 4; i++) { P.plane_thre[i] = s.opt.plane_eigen_value_thre[i]; P.min_point[i] = s.opt.min_point[i]; }
+  for (int i = 0; i < VBA_MAX_WIN; i++) P.mp[i] = s.mp[i];
+  P.rank = s.rank; P.n_ranks = s.n_ranks;
+  return P;
+}
+
+inline std::vector<DevArr> node_arrays(MapView &v, int W) {
+  return {
+      {(void **)&v.nkey, 8, 1}, {(void **)&v.nroot, 4, 1}, {(void **)&v.nparent, 4, 1}, {(void **)&v.nchild, 4, 1}, {(void **)&v.npath, 4, 1},
+      {(void **)&v.nopt, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
+      {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
+      {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
+      {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
+      {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, 8, (size_t)10 * W},
+  };
+}
+inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
+  return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1}};
+}
+inline std::vector<DevArr> fix_arrays(MapView &v) { return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}}; }
+
+// grow a family of [rows][cap] arrays from oldcap to newcap, keeping the first `used` columns; new space zero-filled
+inline int grow_arrays(std::vector<DevArr> arrs, size_t oldcap, size_t newcap, size_t used, hipStream_t st, std::string &err) {
+  for (auto &a : arrs) {
+    void *np = nullptr;
+    MAPCHK(hipMalloc(&np, a.elem * a.rows * newcap));
+    MAPCHK(hipMemsetAsync(np, 0, a.elem * a.rows * newcap, st));
+    if (*a.slot && used > 0)
+      MAPCHK(hipMemcpy2DAsync(np, newcap * a.elem, *a.slot, oldcap * a.elem, used * a.elem, a.rows, hipMemcpyDeviceToDevice, st));
+    MAPCHK(hipStreamSynchronize(st));
+    if (*a.slot) hipFree(*a.slot);
+    *a.slot = np;
+  }
+  return VBA_OK;
+}
+
+inline int map_read_counters(MapStore &s, hipStream_t st, std::string &err) {
+  MAPCHK(hipMemcpyAsync(s.h_cnt, s.v.cnt, CNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
+  MAPCHK(hipStreamSynchronize(st));
+  return VBA_OK;
+}
+
+inline int map_hash_alloc(MapStore &s, unsigned int cap, hipStream_t st, std::string &err) {
+  unsigned long long *nk = nullptr; int *nv = nullptr;
+  MAPCHK(hipMalloc((void **)&nk, (size_t)cap * 8));
+  MAPCHK(hipMalloc((void **)&nv, (size_t)cap * 4));
+  hipLaunchKernelGGL(k_fill_u64, dim3(1024), dim3(256), 0, st, nk, KEY_EMPTY, (size_t)cap);
+  MAPCHK(hipMemsetAsync(nv, 0xFF, (size_t)cap * 4, st));
+  if (s.v.hkeys) {
+    hipLaunchKernelGGL(k_rehash, dim3((s.hcap + 255) / 256), dim3(256), 0, st, s.v.hkeys, s.v.hvals, s.v.hmask, nk, nv, cap - 1);
+    MAPCHK(hipStreamSynchronize(st));
+    hipFree(s.v.hkeys); hipFree(s.v.hvals);
+  }
+  s.v.hkeys = nk; s.v.hvals = nv; s.v.hmask = cap - 1; s.hcap = cap;
+  return VBA_OK;
+}
+
+inline int map_base(MapStore &s, hipStream_t st, std::string &err) {
+  if (s.allocated) return VBA_OK;
+  MAPCHK(hipMalloc((void **)&s.v.cnt, CNT_N * sizeof(int)));
+  MAPCHK(hipMemsetAsync(s.v.cnt, 0, CNT_N * sizeof(int), st));
+  MAPCHK(hipMalloc((void **)&s.v.poses, VBA_MAX_WIN * 12 * sizeof(double)));
+  MAPCHK(hipHostMalloc((void **)&s.h_cnt, CNT_N * sizeof(int) + 64, hipHostMallocDefault));
+  std::memset(s.h_cnt, 0, CNT_N * sizeof(int) + 64);
+  int st2 = map_hash_alloc(s, 1u << 20, st, err);
+  if (st2) return st2;
+  s.allocated = true;
+  return VBA_OK;
+}
+
+inline int map_ensure(MapStore &s, hipStream_t st, size_t need_nodes, size_t need_pts, size_t need_fix, std::string &err) {
+  const int W = s.opt.win_size;
+  int rb = map_base(s, st, err);
+  if (rb) return rb;
+  if (need_nodes > (size_t)s.v.cap) {
+    size_t nc = s.v.cap ? (size_t)s.v.cap : (size_t)1 << 18;
+    while (nc < need_nodes) nc *= 2;
+    int r = grow_arrays(node_arrays(s.v, W), (size_t)s.v.cap, nc, (size_t)s.v.cap, st, err);
+    if (r) return r;
+    s.v.cap = (int)nc;
+  }
+  if (need_pts > (size_t)s.v.max_pts) {
+    size_t nc = s.v.max_pts ? (size_t)s.v.max_pts : (size_t)1 << 16;
+    while (nc < need_pts) nc *= 2;
+    int r = grow_arrays(scan_arrays(s.v, W), (size_t)s.v.max_pts, nc, (size_t)s.v.max_pts, st, err);
+    if (r) return r;
+    if (s.v.max_pts == 0) MAPCHK(hipMemsetAsync(s.v.pnode, 0xFF, (size_t)W * nc * 4, st));
+    else {  // new tail of every slot must read "no node"
+      for (int sl = 0; sl < W; sl++)
+        MAPCHK(hipMemsetAsync(s.v.pnode + (size_t)sl * nc + s.v.max_pts, 0xFF, (nc - s.v.max_pts) * 4, st));
+    }
+    s.v.max_pts = (int)nc;
+  }
+  if (need_fix > (size_t)s.v.cap_fix) {
+    size_t nc = s.v.cap_fix ? (size_t)s.v.cap_fix : (size_t)1 << 20;
+    while (nc < need_fix) nc *= 2;
+    int r = grow_arrays(fix_arrays(s.v), (size_t)s.v.cap_fix, nc, (size_t)s.v.cap_fix, st, err);
+    if (r) return r;
+    s.v.cap_fix = (int)nc;
+  }
+  // keep the hash table under ~50 % load
+  const size_t want = 2 * ((size_t)s.h_cnt[CNT_ROOTS] + need_pts);
+  while ((size_t)s.hcap < want && s.hcap < (1u << 30)) {
+    int r = map_hash_alloc(s, s.hcap * 2, st, err);
+    if (r) return r;
+  }
+  return VBA_OK;
+}
+
+inline void map_free(MapStore &s) {
+  if (!s.allocated) return;
+  const int W = s.opt.win_size;
+  for (auto &a : node_arrays(s.v, W)) if (*a.slot) hipFree(*a.slot);
+  for (auto &a : scan_arrays(s.v, W)) if (*a.slot) hipFree(*a.slot);
+  for (auto &a : fix_arrays(s.v)) if (*a.slot) hipFree(*a.slot);
+  if (s.v.hkeys) hipFree(s.v.hkeys);
+  if (s.v.hvals) hipFree(s.v.hvals);
+  if (s.v.cnt) hipFree(s.v.cnt);
+  if (s.v.poses) hipFree(s.v.poses);
+  if (s.h_cnt) hipHostFree(s.h_cnt);
+  if (s.d_stage) hipFree(s.d_stage);
+  s.v = MapView{};
+  s.allocated = false;
+}
+
+inline bool is_device_ptr(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice;
+}
+inline int map_stage(MapStore &s, size_t bytes, std::string &err) {
+  if (bytes <= s.stage_bytes) return VBA_OK;
+  if (s.d_stage) hipFree(s.d_stage);
+  s.d_stage = nullptr; s.stage_bytes = 0;
+  MAPCHK(hipMalloc(&s.d_stage, bytes));
+  s.stage_bytes = bytes;
+  return VBA_OK;
+}
+inline int map_set_counter(MapStore &s, hipStream_t st, int which, int val, std::string &err) {
+  s.h_cnt[CNT_N + 1] = val;
+  MAPCHK(hipMemcpyAsync(s.v.cnt + which, &s.h_cnt[CNT_N + 1], sizeof(int), hipMemcpyHostToDevice, st));
+  MAPCHK(hipStreamSynchronize(st));
+  return VBA_OK;
+}
+
+// cut_voxel / cut_voxel_multi for one scan
+inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, const double *pnt_body, const double *var, const double *pose,
+                         bool multi, std::string &err) {
+  const int W = s.opt.win_size;
+  if (win_count < 0 || win_count >= W || n < 0 || !pose || (n > 0 && !pnt_body)) return VBA_ERR_BAD_ARG;
+  int r = map_base(s, st, err);
+  if (r) return r;
+  r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + (size_t)n + 64, (size_t)n, (size_t)1, err);
+  if (r) return r;
+  const int slot = s.mp[win_count];
+  s.npts[slot] = n;
+  if (n == 0) return VBA_OK;
+  // stage the points into the slot's SoA arrays
+  const double *d_pts = pnt_body, *d_var = var;
+  if (!is_device_ptr(pnt_body)) {
+    const size_t bytes = (size_t)n * 3 * 8 + (var ? (size_t)n * 9 * 8 : 0);
+    r = map_stage(s, bytes, err);
+    if (r) return r;
+    MAPCHK(hipMemcpyAsync(s.d_stage, pnt_body, (size_t)n * 3 * 8, hipMemcpyHostToDevice, st));
+    d_pts = (const double *)s.d_stage;
+    if (var) {
+      MAPCHK(hipMemcpyAsync((char *)s.d_stage + (size_t)n * 3 * 8, var, (size_t)n * 9 * 8, hipMemcpyHostToDevice, st));
+      d_var = (const double *)((char *)s.d_stage + (size_t)n * 3 * 8);
+    }
+  }
+  if (var) s.have_var = true;
+  MAPCHK(hipMemcpyAsync(s.v.poses, pose, 12 * sizeof(double), hipMemcpyHostToDevice, st));
+  const MapParams P = map_params(s);
+  const int nb = (n + 255) / 256;
+  if (n < s.v.max_pts)   // stale assignments of the slot's previous occupant must not survive
+    MAPCHK(hipMemsetAsync(s.v.pnode + (size_t)slot * s.v.max_pts + n, 0xFF, (size_t)(s.v.max_pts - n) * 4, st));
+  hipLaunchKernelGGL(k_scan_to_soa, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var);
+  r = map_set_counter(s, st, CNT_NEWSLOTS, 0, err); if (r) return r;
+  r = map_set_counter(s, st, CNT_TOUCH, 0, err); if (r) return r;
+  hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, 0);
+  hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0);
+  s.stamp++;
+  hipLaunchKernelGGL(k_ins_touch, dim3(nb), dim3(256), 0, st, s.v, n, s.stamp);
+  hipLaunchKernelGGL(k_ins_accum, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0, var ? 1 : 0);
+  MAPCHK(hipGetLastError());
+  r = map_read_counters(s, st, err);
+  if (r) return r;
+  if (s.h_cnt[CNT_OVERFLOW]) { err = "voxel map node capacity exceeded during insert"; return VBA_ERR_CAPACITY; }
+  return VBA_OK;
+}
+
+inline int map_cut_voxel_fix(MapStore &s, hipStream_t st, int n, const double *pnt_world, double jour, std::string &err) {
+  if (n < 0 || (n > 0 && !pnt_world)) return VBA_ERR_BAD_ARG;
+  if (n == 0) return VBA_OK;
+  int r = map_base(s, st, err);
+  if (r) return r;
+  r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + (size_t)n + 64, (size_t)n, (size_t)s.h_cnt[CNT_FIX] + (size_t)n, err);
+  if (r) return r;
+  const double *d_pts = pnt_world;
+  if (!is_device_ptr(pnt_world)) {
+    r = map_stage(s, (size_t)n * 3 * 8, err);
+    if (r) return r;
+    MAPCHK(hipMemcpyAsync(s.d_stage, pnt_world, (size_t)n * 3 * 8, hipMemcpyHostToDevice, st));
+    d_pts = (const double *)s.d_stage;
+  }
+  const MapParams P = map_params(s);
+  const int base = s.h_cnt[CNT_FIX];
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fix_to_soa, dim3(nb), dim3(256), 0, st, s.v, base, n, d_pts);
+  r = map_set_counter(s, st, CNT_NEWSLOTS, 0, err); if (r) return r;
+  r = map_set_counter(s, st, CNT_FIX, base + n, err); if (r) return r;
+  hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, base, n, 1);
+  hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 1, jour);
+  hipLaunchKernelGGL(k_fix_accum, dim3(nb), dim3(256), 0, st, s.v, P, base, n);
+  MAPCHK(hipGetLastError());
+  r = map_read_counters(s, st, err);
+  if (r) return r;
+  if (s.h_cnt[CNT_OVERFLOW]) { err = "voxel map capacity exceeded during fixed-point insert"; return VBA_ERR_CAPACITY; }
+  return VBA_OK;
+}
+
+// recut over the scope + factor index assignment; *n_factors = number of planar leaves selected by tras_opt
+inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *poses, bool multi, std::string &err, int *n_factors) {
+  const int W = s.opt.win_size;
+  *n_factors = 0;
+  if (win_count < 0 || win_count > W || !poses) return VBA_ERR_BAD_ARG;
+  if (!s.allocated) return VBA_OK;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    int r = map_read_counters(s, st, err);
+    if (r) return r;
+    // room for every current leaf to split once per level (checked again through the overflow flag)
+    r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + 8 * (size_t)(attempt ? s.h_cnt[CNT_NODES] : 65536), 0, 0, err);
+    if (r) return r;
+    r = map_set_counter(s, st, CNT_OVERFLOW, 0, err); if (r) return r;
+    MAPCHK(hipMemcpyAsync(s.v.poses, poses, (size_t)(win_count > 0 ? win_count : 1) * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+    const MapParams P = map_params(s);
+    int max_n = 0;
+    for (int i = 0; i < win_count; i++) if (s.npts[s.mp[i]] > max_n) max_n = s.npts[s.mp[i]];
+    for (int L = 0; L <= s.opt.max_layer; L++) {
+      s.epoch++;
+      // node count can grow by 8 per split of the previous level: launch over the capacity-bounded upper estimate
+      r = map_read_counters(s, st, err);
+      if (r) return r;
+      const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+      if (nn == 0) break;
+      hipLaunchKernelGGL(k_recut_leaf, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
+      if (L < s.opt.max_layer) {
+        if (max_n > 0 && win_count > 0)
+          hipLaunchKernelGGL(k_recut_points, dim3((max_n + 255) / 256, win_count), dim3(256), 0, st, s.v, P, win_count, s.epoch, s.have_var ? 1 : 0);
+        if (s.h_cnt[CNT_FIX] > 0)
+          hipLaunchKernelGGL(k_recut_fixpts, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v, P, s.epoch, L + 1);
+      }
+    }
+    MAPCHK(hipGetLastError());
+    r = map_read_counters(s, st, err);
+    if (r) return r;
+    if (!s.h_cnt[CNT_OVERFLOW]) break;
+    // a leaf could not be split for lack of node space: clamp the counter, grow and run the pass again (idempotent)
+    if (s.h_cnt[CNT_NODES] > s.v.cap) { r = map_set_counter(s, st, CNT_NODES, s.v.cap, err); if (r) return r; }
+    if (attempt == 7) { err = "voxel map node capacity exceeded during recut"; return VBA_ERR_CAPACITY; }
+  }
+  // tras_opt pass 1
+  int r = map_set_counter(s, st, CNT_FACTORS, 0, err); if (r) return r;
+  const MapParams P = map_params(s);
+  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+  if (nn > 0) hipLaunchKernelGGL(k_extract_count, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, P, multi ? 1 : 0);
+  MAPCHK(hipGetLastError());
+  r = map_read_counters(s, st, err);
+  if (r) return r;
+  *n_factors = s.h_cnt[CNT_FACTORS];
+  s.h_cnt[CNT_N] = multi ? 1 : 0;   // remembered for map_extract_factors
+  return VBA_OK;
+}
+
+inline int map_extract_factors(MapStore &s, hipStream_t st, FactorView f, std::string &err, int *n_factors) {
+  *n_factors = 0;
+  if (!s.allocated) return VBA_OK;
+  const MapParams P = map_params(s);
+  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+  if (nn > 0) hipLaunchKernelGGL(k_extract_write, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, P, f, s.h_cnt[CNT_N]);
+  MAPCHK(hipGetLastError());
+  *n_factors = s.h_cnt[CNT_FACTORS];
+  return VBA_OK;
+}
+
+inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *poses, double jour, FactorView f, int nfac, std::string &err) {
+  const int W = s.opt.win_size;
+  if (win_count < 1 || win_count > W || !poses) return VBA_ERR_BAD_ARG;
+  if (!s.allocated) return VBA_OK;
+  int r = map_read_counters(s, st, err);
+  if (r) return r;
+  const int slot0 = s.mp[0];
+  r = map_ensure(s, st, 0, 0, (size_t)s.h_cnt[CNT_FIX] + (size_t)s.npts[slot0] + 1, err);
+  if (r) return r;
+  r = map_set_counter(s, st, CNT_OVERFLOW, 0, err); if (r) return r;
+  MAPCHK(hipMemcpyAsync(s.v.poses, poses, (size_t)win_count * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+  const MapParams P = map_params(s);
+  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+  const int n_slide_before = s.h_cnt[CNT_SLIDE];
+  if (nn == 0) return VBA_OK;
+  s.epoch++;
+  const dim3 gn((nn + 255) / 256), b(256);
+  hipLaunchKernelGGL(k_margi_leaf, gn, b, 0, st, s.v, P, f, nfac, win_count, s.epoch);
+  if (n_slide_before >= s.opt.thread_num) {
+    if (s.npts[slot0] > 0) hipLaunchKernelGGL(k_margi_points, dim3((s.v.max_pts + 255) / 256), b, 0, st, s.v, P, s.epoch, s.have_var ? 1 : 0);
+    if (s.h_cnt[CNT_FIX] > 0) hipLaunchKernelGGL(k_margi_fixclear, dim3((s.h_cnt[CNT_FIX] + 255) / 256), b, 0, st, s.v, s.epoch);
+    for (int L = s.opt.max_layer - 1; L >= 0; L--) hipLaunchKernelGGL(k_margi_up, gn, b, 0, st, s.v, P, L);
+    hipLaunchKernelGGL(k_margi_roots, gn, b, 0, st, s.v, P, jour, s.epoch, n_slide_before);
+    hipLaunchKernelGGL(k_margi_clear_nodes, gn, b, 0, st, s.v, P, s.epoch);
+    hipLaunchKernelGGL(k_margi_clear_points, dim3((s.v.max_pts + 255) / 256, W), b, 0, st, s.v, P, s.epoch);
+    s.npts[slot0] = 0;
+  }
+  MAPCHK(hipGetLastError());
+  r = map_read_counters(s, st, err);
+  if (r) return r;
+  if (s.h_cnt[CNT_OVERFLOW] == 2) { err = "Error: opt_state out of range"; return VBA_ERR_OPT_STATE; }
+  if (s.h_cnt[CNT_OVERFLOW]) { err = "fixed-point pool capacity exceeded"; return VBA_ERR_CAPACITY; }
+  return VBA_OK;
+}
+
+inline int map_slide(MapStore &s, int mgsize) {   // VS:2014-2019
+  const int W = s.opt.win_size;
+  if (mgsize < 0 || mgsize > W) return VBA_ERR_BAD_ARG;
+  for (int i = 0; i < W; i++) { s.mp[i] += mgsize; if (s.mp[i] >= W) s.mp[i] -= W; }
+  return VBA_OK;
+}
+
+inline int map_reset(MapStore &s, hipStream_t st, std::string &err) {
+  if (!s.allocated) return VBA_OK;
+  const int W = s.opt.win_size;
+  hipStreamSynchronize(st);
+  for (auto &a : node_arrays(s.v, W)) MAPCHK(hipMemsetAsync(*a.slot, 0, a.elem * a.rows * (size_t)s.v.cap, st));
+  if (s.v.pnode) MAPCHK(hipMemsetAsync(s.v.pnode, 0xFF, (size_t)W * s.v.max_pts * 4, st));
+  if (s.v.fnode) MAPCHK(hipMemsetAsync(s.v.fnode, 0xFF, (size_t)s.v.cap_fix * 4, st));
+  hipLaunchKernelGGL(k_fill_u64, dim3(1024), dim3(256), 0, st, s.v.hkeys, KEY_EMPTY, (size_t)s.hcap);
+  MAPCHK(hipMemsetAsync(s.v.hvals, 0xFF, (size_t)s.hcap * 4, st));
+  MAPCHK(hipMemsetAsync(s.v.cnt, 0, CNT_N * sizeof(int), st));
+  MAPCHK(hipStreamSynchronize(st));
+  std::memset(s.h_cnt, 0, CNT_N * sizeof(int));
+  for (int i = 0; i < VBA_MAX_WIN; i++) { s.mp[i] = i; s.npts[i] = 0; }
+  s.have_var = false;
+  return VBA_OK;
+}
+
+inline int map_num_roots(MapStore &s, hipStream_t st, bool slide) {
+  if (!s.allocated) return 0;
+  std::string err;
+  if (map_read_counters(s, st, err)) return -1;
+  return slide ? s.h_cnt[CNT_SLIDE] : s.h_cnt[CNT_ROOTS];
+}
+
+inline int map_dump_leaves(MapStore &s, hipStream_t st, double *out, int max_leaves, std::string &err) {
+  if (!s.allocated) return 0;
+  if (map_read_counters(s, st, err)) return -1;
+  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+  if (nn == 0) return 0;
+  const int cap_out = out ? max_leaves : 0;
+  double *d_out = nullptr;
+  if (cap_out > 0 && hipMalloc((void **)&d_out, (size_t)cap_out * 39 * 8) != hipSuccess) return -1;
+  if (map_set_counter(s, st, CNT_LEAVES, 0, err)) return -1;
+  hipLaunchKernelGGL(k_dump_leaves, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, d_out, cap_out);
+  if (map_read_counters(s, st, err)) return -1;
+  const int n = s.h_cnt[CNT_LEAVES];
+  if (cap_out > 0) {
+    hipMemcpy(out, d_out, (size_t)(n < cap_out ? n : cap_out) * 39 * 8, hipMemcpyDeviceToHost);
+    hipFree(d_out);
+  }
+  return n;
+}
 
 }  // namespace vba

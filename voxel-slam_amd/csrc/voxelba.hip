@@ -708,7 +708,7 @@ int vba_map_recut(vba_ctx *c, int win_count, const double *poses, int multi) {
   c->nvox = nf;
   return VBA_OK;
 }
-int vba_map_margi(vba_ctx *c, int win_count, const double *poses) { return map_margi(c->map, c->stream, win_count, poses, c->fv, c->nvox, c->err); }
+int vba_map_margi(vba_ctx *c, int win_count, const double *poses, double jour) { return map_margi(c->map, c->stream, win_count, poses, jour, c->fv, c->nvox, c->err); }
 int vba_map_slide(vba_ctx *c, int mgsize) { return map_slide(c->map, mgsize); }
 int vba_map_reset(vba_ctx *c) { return map_reset(c->map, c->stream, c->err); }
 int vba_map_num_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, false); }
