@@ -103,6 +103,10 @@ int vba_factor_evaluate_only_residual(vba_ctx *ctx, const double *poses, int hea
  * motion_init (VS:737).  Any pointer may be NULL. */
 int vba_factor_read_back(vba_ctx *ctx, double *eig_val, double *eig_vec, double *pcr_add);
 
+/* Number of occupied (voxel, frame) slots (clusters with N != 0) in the factor store — the "slots" that the
+ * algorithmic-traffic figures of DESIGN.md are priced on. */
+int vba_factor_occupied_slots(vba_ctx *ctx, long long *slots);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizers — drop-in for the three LM classes.                                                  */
 

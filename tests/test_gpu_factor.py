@@ -109,9 +109,18 @@ def test_synthetic_scene_factor_parity(capi, oracle, synth, name):
     assert _relerr(H, H2) < 1e-9 and _relerr(g, g2) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["room20k_w4", "avia100k_w10"])
+def _workload(synth, name):
+    if name == "spin40k_w10":      # the 200k-pt Hesai workload at 1/5 of the points (same room, W=10, 0.3 m voxels)
+        import dataclasses
+        return dataclasses.replace(synth.CONFIGS["hesai200k_w10"], name=name, n_pts=40000)
+    return synth.CONFIGS[name]
+
+
+@pytest.mark.parametrize("name", ["room20k_w4", "spin40k_w10"])
 def test_lidar_ba_damping_iter_parity(capi, oracle, synth, name):
-    wl = synth.CONFIGS[name]
+    # (the +-35 degree Avia cone mostly sees one wall: lidar-only BA without IMU factors is ill-posed there, so the LM
+    #  parity runs on the 360-degree patterns; the Avia scene is covered at the H/g/residual level above)
+    wl = _workload(synth, name)
     s = synth.make_scans(wl)
     fac = synth.root_factors(s["points"], s["R0"], s["p0"], wl)
     W = wl.win_size

@@ -23,7 +23,7 @@ ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED_WINDOW, ERR_TOO_FEW_VOXELS, ERR_OPT_
 EXPORTS = [
     "vba_default_options", "vba_create", "vba_destroy", "vba_status_string", "vba_last_error", "vba_synchronize",
     "vba_factor_clear", "vba_factor_push_voxels", "vba_factor_size", "vba_factor_acc_evaluate2",
-    "vba_factor_evaluate_only_residual", "vba_factor_read_back",
+    "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
     "vba_map_cut_voxel", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_reset",
@@ -194,6 +194,12 @@ class Context:
         ev = np.empty((n, 3)); evec = np.empty((n, 9)); pa = np.empty((n, 10))
         self._chk(self.lib.vba_factor_read_back(self.h, _p(ev), _p(evec), _p(pa)))
         return ev, evec, pa
+
+    def factor_occupancy(self) -> float:
+        """Occupied (voxel, frame) slots per voxel in the factor store."""
+        n = C.c_longlong(0)
+        self._chk(self.lib.vba_factor_occupied_slots(self.h, C.byref(n)))
+        return n.value / max(self.size(), 1)
 
     # ---- optimizers
     def last_trace(self):

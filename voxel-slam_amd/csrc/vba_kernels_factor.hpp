@@ -112,6 +112,16 @@ __global__ void k_soa_to_aos_out(FactorView f, int n, double *__restrict__ eig_v
   }
 }
 
+__global__ void k_count_slots(FactorView f, int n, unsigned long long *out) {
+  const long long tot = (long long)n * f.W;
+  unsigned long long c = 0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / n), v = (int)(t % n);
+    if (f.cl[((size_t)9 * f.W + i) * f.vs + v] != 0.0) c++;
+  }
+  if (c) atomicAdd(out, c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: residual pass.  One thread per voxel; 64-thread workgroups so that V ~ 3e4 voxels still spread
 // over all 256 CUs.  Algorithmic traffic per voxel: read (W_occ+1)*80 + W*8 + 8 B, write 176 B.

@@ -404,6 +404,21 @@ int vba_factor_read_back(vba_ctx *c, double *eig_val, double *eig_vec, double *p
   return VBA_OK;
 }
 
+int vba_factor_occupied_slots(vba_ctx *c, long long *slots) {
+  if (!slots) return VBA_ERR_BAD_ARG;
+  *slots = 0;
+  if (c->nvox == 0) return VBA_OK;
+  int st = ensure_stage(c, 64);
+  if (st) return st;
+  HIPCHK(c, hipMemsetAsync(c->d_stage, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_count_slots, dim3(512), dim3(256), 0, c->stream, c->fv, c->nvox, (unsigned long long *)c->d_stage);
+  unsigned long long h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, c->d_stage, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *slots = (long long)h;
+  return VBA_OK;
+}
+
 // ---------------------------------------------------------------- Lidar_BA_Optimizer (VM:342-498)
 int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   const int W = c->opt.win_size, n = 6 * W;
@@ -690,13 +705,19 @@ int vba_timing_get(vba_ctx *c, const char *name, double *total_us, int *count) {
 
 // ---------------------------------------------------------------- map level (vba_kernels_map.hpp)
 int vba_map_cut_voxel(vba_ctx *c, int win_count, int n, const double *pnt_body, const double *var, const double *pose, int multi) {
-  return map_cut_voxel(c->map, c->stream, win_count, n, pnt_body, var, pose, multi != 0, c->err);
+  TimedSpan s{};
+  span_begin(c, "insert", s);
+  const int st = map_cut_voxel(c->map, c->stream, win_count, n, pnt_body, var, pose, multi != 0, c->err);
+  span_end(c, "insert", s);
+  return st;
 }
 int vba_map_cut_voxel_fix(vba_ctx *c, int n, const double *pnt_world, double jour) {
   return map_cut_voxel_fix(c->map, c->stream, n, pnt_world, jour, c->err);
 }
 int vba_map_recut(vba_ctx *c, int win_count, const double *poses, int multi) {
   int nf = 0;
+  TimedSpan sp{};
+  span_begin(c, "recut", sp);
   int st = map_recut(c->map, c->stream, win_count, poses, multi != 0, c->err, &nf);
   if (st) return st;
   // tras_opt: the map writes the planar leaves straight into the SoA factor store (no host round trip)
@@ -704,11 +725,18 @@ int vba_map_recut(vba_ctx *c, int win_count, const double *poses, int multi) {
   st = factor_reserve(c, nf > 0 ? nf : 1);
   if (st) return st;
   st = map_extract_factors(c->map, c->stream, c->fv, c->err, &nf);
+  span_end(c, "recut", sp);
   if (st) return st;
   c->nvox = nf;
   return VBA_OK;
 }
-int vba_map_margi(vba_ctx *c, int win_count, const double *poses, double jour) { return map_margi(c->map, c->stream, win_count, poses, jour, c->fv, c->nvox, c->err); }
+int vba_map_margi(vba_ctx *c, int win_count, const double *poses, double jour) {
+  TimedSpan s{};
+  span_begin(c, "margi", s);
+  const int st = map_margi(c->map, c->stream, win_count, poses, jour, c->fv, c->nvox, c->err);
+  span_end(c, "margi", s);
+  return st;
+}
 int vba_map_slide(vba_ctx *c, int mgsize) { return map_slide(c->map, mgsize); }
 int vba_map_reset(vba_ctx *c) { return map_reset(c->map, c->stream, c->err); }
 int vba_map_num_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, false); }
