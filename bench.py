@@ -98,10 +98,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()     # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("VBA_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only to rehearse on one card
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     wl, scans, poses0 = build_problem(args.workload)
     W = wl.win_size

@@ -1,0 +1,221 @@
+// voxelba_adapter.hpp — header-only C++ adapter that gives libvoxelba.so (include/voxelba.h) the class/method
+// surface of the reference so that it drops in behind the ROS odometry node:
+//
+//   reference (VoxelSLAM/src/voxel_map.hpp)                         adapter
+//   -------------------------------------------------------------   -----------------------------------------
+//   class LidarFactor            VM:124-339                         vba::LidarFactor
+//   class Lidar_BA_Optimizer     VM:342-498  (damping_iter :422)    vba::Lidar_BA_Optimizer
+//   class LI_BA_Optimizer        VM:504-714  (damping_iter :624)    vba::LI_BA_Optimizer
+//   class LI_BA_OptimizerGravity VM:717-976  (damping_iter :878)    vba::LI_BA_OptimizerGravity
+//   cut_voxel / cut_voxel_multi / cut_voxel(fix)  VM:1896/1964/2108 vba::VoxelMap::cut_voxel[_multi|_fix]
+//   multi_recut / multi_margi    VS:1682 / VS:1590                  vba::VoxelMap::multi_recut / multi_margi
+//
+// The reference's types are Eigen-based (tools.hpp:4).  This header compiles without Eigen (plain-array structs that
+// mirror PointCluster / IMUST / IMU_PRE field for field); when <Eigen/Core> is available the Eigen-typed overloads
+// below are enabled so call sites such as voxelslam.cpp:1969-1970 compile unchanged after `using namespace vba;`.
+#pragma once
+#include "voxelba.h"
+#include <cstring>
+#include <deque>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define VBA_ADAPTER_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace vba {
+
+struct PointCluster {  // tools.hpp:304-365 (P symmetric 3x3 row-major, v, N)
+  double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double v[3] = {0, 0, 0};
+  int N = 0;
+  void pack(double *c) const { c[0] = P[0]; c[1] = P[3]; c[2] = P[6]; c[3] = P[4]; c[4] = P[7]; c[5] = P[8]; c[6] = v[0]; c[7] = v[1]; c[8] = v[2]; c[9] = N; }
+  void unpack(const double *c) {
+    P[0] = c[0]; P[1] = P[3] = c[1]; P[2] = P[6] = c[2]; P[4] = c[3]; P[5] = P[7] = c[4]; P[8] = c[5];
+    v[0] = c[6]; v[1] = c[7]; v[2] = c[8]; N = (int)c[9];
+  }
+};
+
+struct IMUST {  // tools.hpp:135-199: exactly the `state` layout of voxelba.h followed by cov
+  double t = 0, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, bg[3] = {0, 0, 0}, ba[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+  double cov[225] = {0};
+};
+
+struct IMU_PRE {  // preintegration.hpp:11-331: exactly the `imu_pre` layout of voxelba.h
+  double f[VBA_IMU_PRE_LEN];
+  IMU_PRE(const double *bg1 = nullptr, const double *ba1 = nullptr) {
+    std::memset(f, 0, sizeof(f));
+    f[0] = f[4] = f[8] = 1.0;
+    if (bg1) std::memcpy(f + 15, bg1, 24);
+    if (ba1) std::memcpy(f + 18, ba1, 24);
+  }
+};
+
+inline void check(vba_ctx *c, int st) {
+  if (st != VBA_OK) throw std::runtime_error(std::string("libvoxelba: ") + vba_status_string(st) + " | " + (c ? vba_last_error(c) : ""));
+}
+
+// One context = one HIP stream + HBM factor store + device voxel map.  The reference's globals (VM:98-104, VM:500) are
+// the fields of vba_options.
+class Context {
+ public:
+  explicit Context(const vba_options &o) { check(nullptr, vba_create(&o, &c_)); }
+  ~Context() { vba_destroy(c_); }
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+  vba_ctx *get() const { return c_; }
+ private:
+  vba_ctx *c_ = nullptr;
+};
+
+// class LidarFactor (VM:124-339).  The voxel data lives in HBM; eig_values / eig_vectors / pcr_adds are fetched on demand.
+class LidarFactor {
+ public:
+  int win_size;
+  LidarFactor(Context &ctx, int w) : win_size(w), c_(ctx.get()) {}
+  void push_voxel(const std::vector<PointCluster> &vec_orig, const PointCluster &fix, double coe, const double *eig_value3,
+                  const double *eig_vector9, const PointCluster &pcr_add) {   // VM:139-147
+    std::vector<double> cl((size_t)win_size * 10);
+    for (int i = 0; i < win_size; i++) vec_orig[i].pack(&cl[(size_t)i * 10]);
+    double fx[10], pa[10];
+    fix.pack(fx); pcr_add.pack(pa);
+    check(c_, vba_factor_push_voxels(c_, 1, cl.data(), fx, &coe, eig_value3, eig_vector9, pa));
+  }
+  size_t size() const { return (size_t)vba_factor_size(c_); }   // plvec_voxels.size()
+  void acc_evaluate2(const std::vector<IMUST> &xs, int head, int end, double *Hess, double *JacT, double &residual) {   // VM:150-282
+    std::vector<double> poses = poses_of(xs);
+    check(c_, vba_factor_acc_evaluate2(c_, poses.data(), head, end, Hess, JacT, &residual));
+  }
+  void evaluate_only_residual(const std::vector<IMUST> &xs, int head, int end, double &residual) {   // VM:285-325
+    std::vector<double> poses = poses_of(xs);
+    check(c_, vba_factor_evaluate_only_residual(c_, poses.data(), head, end, &residual));
+  }
+  void read_back(std::vector<double> &eig_values, std::vector<double> &eig_vectors, std::vector<PointCluster> &pcr_adds) {
+    const size_t n = size();
+    eig_values.resize(n * 3); eig_vectors.resize(n * 9);
+    std::vector<double> pa(n * 10);
+    check(c_, vba_factor_read_back(c_, eig_values.data(), eig_vectors.data(), pa.data()));
+    pcr_adds.resize(n);
+    for (size_t a = 0; a < n; a++) pcr_adds[a].unpack(&pa[a * 10]);
+  }
+  void clear() { check(c_, vba_factor_clear(c_)); }   // VM:328-336
+  vba_ctx *ctx() const { return c_; }
+  static std::vector<double> poses_of(const std::vector<IMUST> &xs) {
+    std::vector<double> p(xs.size() * 12);
+    for (size_t i = 0; i < xs.size(); i++) { std::memcpy(&p[i * 12], xs[i].R, 72); std::memcpy(&p[i * 12 + 9], xs[i].p, 24); }
+    return p;
+  }
+ private:
+  vba_ctx *c_;
+};
+
+// class Lidar_BA_Optimizer (VM:342-498)
+class Lidar_BA_Optimizer {
+ public:
+  int win_size = 0, jac_leng = 0, thd_num = 2;
+  // bool damping_iter(vector<IMUST>&, LidarFactor&, MatrixXd *hess, vector<double> &resis, int max_iter = 3, bool is_display = false)  VM:422
+  bool damping_iter(std::vector<IMUST> &x_stats, LidarFactor &voxhess, std::vector<double> *hess, std::vector<double> &resis, int max_iter = 3,
+                    bool /*is_display*/ = false) {
+    win_size = voxhess.win_size; jac_leng = 6 * win_size;
+    std::vector<double> poses = LidarFactor::poses_of(x_stats);
+    if (hess) hess->assign((size_t)jac_leng * jac_leng, 0.0);
+    double r2[2] = {0, 0};
+    int conv = 0;
+    check(voxhess.ctx(), vba_lidar_ba_damping_iter(voxhess.ctx(), poses.data(), hess ? hess->data() : nullptr, r2, max_iter, thd_num, &conv));
+    for (size_t i = 0; i < x_stats.size(); i++) { std::memcpy(x_stats[i].R, &poses[i * 12], 72); std::memcpy(x_stats[i].p, &poses[i * 12 + 9], 24); }
+    resis.push_back(r2[0]); resis.push_back(r2[1]);
+    return conv != 0;
+  }
+};
+
+namespace detail {
+inline void li_call(std::vector<IMUST> &x_stats, LidarFactor &voxhess, std::deque<IMU_PRE *> &imus_factor, std::vector<double> *resis,
+                    std::vector<double> *hess, int gravity, int max_iter) {
+  const int W = voxhess.win_size, n = 15 * W + (gravity ? 3 : 0);
+  std::vector<double> st((size_t)W * 25), im((size_t)(W - 1) * VBA_IMU_PRE_LEN);
+  for (int i = 0; i < W; i++) std::memcpy(&st[(size_t)i * 25], &x_stats[i].t, 25 * sizeof(double));
+  for (int i = 0; i < W - 1; i++) std::memcpy(&im[(size_t)i * VBA_IMU_PRE_LEN], imus_factor[i]->f, sizeof(imus_factor[i]->f));
+  if (hess) hess->assign((size_t)n * n, 0.0);
+  double r2[2] = {0, 0};
+  check(voxhess.ctx(), vba_li_ba_damping_iter(voxhess.ctx(), st.data(), im.data(), gravity, max_iter, hess ? hess->data() : nullptr, r2));
+  for (int i = 0; i < W; i++) std::memcpy(&x_stats[i].t, &st[(size_t)i * 25], 25 * sizeof(double));
+  for (int i = 0; i < W - 1; i++) std::memcpy(imus_factor[i]->f, &im[(size_t)i * VBA_IMU_PRE_LEN], sizeof(imus_factor[i]->f));
+  if (gravity && resis) { resis->push_back(r2[0]); resis->push_back(r2[1]); }
+}
+}  // namespace detail
+
+// class LI_BA_Optimizer (VM:504-714): void damping_iter(x_stats, voxhess, imus_factor, MatrixXd *hess)  VM:624
+class LI_BA_Optimizer {
+ public:
+  void damping_iter(std::vector<IMUST> &x_stats, LidarFactor &voxhess, std::deque<IMU_PRE *> &imus_factor, std::vector<double> *hess) {
+    detail::li_call(x_stats, voxhess, imus_factor, nullptr, hess, 0, 3);
+  }
+};
+// class LI_BA_OptimizerGravity (VM:717-976): void damping_iter(x_stats, voxhess, imus_factor, resis, hess, max_iter = 2)  VM:878
+class LI_BA_OptimizerGravity {
+ public:
+  void damping_iter(std::vector<IMUST> &x_stats, LidarFactor &voxhess, std::deque<IMU_PRE *> &imus_factor, std::vector<double> &resis,
+                    std::vector<double> *hess, int max_iter = 2) {
+    detail::li_call(x_stats, voxhess, imus_factor, &resis, hess, 1, max_iter);
+  }
+};
+
+// Voxel map: unordered_map<VOXEL_LOC, OctoTree*> surf_map / surf_map_slide + the free functions that operate on them.
+struct pointVar { double pnt[3]; double var[9]; };   // VM:18-34
+typedef std::vector<pointVar> PVec;
+
+class VoxelMap {
+ public:
+  explicit VoxelMap(Context &ctx) : c_(ctx.get()) {}
+  // cut_voxel(feat_map, pvec, win_count, feat_tem_map, wdsize, pwld, sws) VM:1896 — pwld = R p + t is recomputed on the device from `x`
+  void cut_voxel(const PVec &pvec, int win_count, const IMUST &x, bool with_var = true) { insert(pvec, win_count, x, with_var, 0); }
+  // cut_voxel_multi(...) VM:1964
+  void cut_voxel_multi(const PVec &pvec, int win_count, const IMUST &x, bool with_var = true) { insert(pvec, win_count, x, with_var, 1); }
+  // cut_voxel(feat_map, PVec&, wdsize, jour) VM:2108
+  void cut_voxel_fix(const PVec &pvec, double jour) {
+    std::vector<double> p(pvec.size() * 3);
+    for (size_t i = 0; i < pvec.size(); i++) std::memcpy(&p[i * 3], pvec[i].pnt, 24);
+    check(c_, vba_map_cut_voxel_fix(c_, (int)pvec.size(), p.data(), jour));
+  }
+  // multi_recut(feat_map, win_count, xs, voxopt, sws) VS:1682 (fills the context's LidarFactor store)
+  void multi_recut(int win_count, const std::vector<IMUST> &xs, bool multi = true) {
+    std::vector<double> poses = LidarFactor::poses_of(xs);
+    check(c_, vba_map_recut(c_, win_count, poses.data(), multi ? 1 : 0));
+  }
+  // multi_margi(feat_map, jour, win_count, xs, voxopt, sw) VS:1590
+  void multi_margi(double jour, int win_count, const std::vector<IMUST> &xs) {
+    std::vector<double> poses = LidarFactor::poses_of(xs);
+    check(c_, vba_map_margi(c_, win_count, poses.data(), jour));
+  }
+  void slide(int mgsize) { check(c_, vba_map_slide(c_, mgsize)); }   // VS:2014-2019
+  void reset() { check(c_, vba_map_reset(c_)); }
+  size_t size() const { return (size_t)vba_map_num_roots(c_); }
+  size_t slide_size() const { return (size_t)vba_map_num_slide_roots(c_); }
+ private:
+  void insert(const PVec &pvec, int win_count, const IMUST &x, bool with_var, int multi) {
+    const size_t n = pvec.size();
+    std::vector<double> p(n * 3), v(with_var ? n * 9 : 0);
+    for (size_t i = 0; i < n; i++) { std::memcpy(&p[i * 3], pvec[i].pnt, 24); if (with_var) std::memcpy(&v[i * 9], pvec[i].var, 72); }
+    double pose[12];
+    std::memcpy(pose, x.R, 72); std::memcpy(pose + 9, x.p, 24);
+    check(c_, vba_map_cut_voxel(c_, win_count, (int)n, p.data(), with_var ? v.data() : nullptr, pose, multi));
+  }
+  vba_ctx *c_;
+};
+
+#ifdef VBA_ADAPTER_HAVE_EIGEN
+// Eigen-typed conveniences so reference call sites keep their argument types (Eigen is column-major: converted here).
+inline void to_rowmajor3(const Eigen::Matrix3d &M, double *r) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[3 * i + j] = M(i, j); }
+inline Eigen::MatrixXd to_eigen(const std::vector<double> &h, int n) {
+  Eigen::MatrixXd M(n, n);
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) M(i, j) = h[(size_t)i * n + j];
+  return M;
+}
+#endif
+
+}  // namespace vba
