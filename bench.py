@@ -163,12 +163,15 @@ def main():
             ctx.evaluate_only_residual(poses0)       # re-create the eigen state for the restart (untimed as a step)
             ctx.lm_begin(poses0, thd_num=2)
             for _ in range(min(3, k - done)):
-                ctx.lm_iterate()
+                ctx.lm_iterate(sync=False)
                 done += 1
             ctx.lm_end()
 
     run_steps(args.warmup)
+    # timed region: only the residual pass K4 (the kernel whose roofline is reported) is bracketed by hipEvents — every
+    # event pair costs host time per launch; the other kernels are timed in a second, untimed pass below
     ctx.timing_enable(True)
+    ctx.timing_select("residual")
     ctx.timing_reset()
     if world > 1:
         dist.barrier()
@@ -183,10 +186,16 @@ def main():
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    t_res, n_res = ctx.timing_get("residual")
+    # second pass (not part of `value`): events around every kernel family
+    ctx.timing_select(None)
+    ctx.timing_reset()
+    run_steps(min(args.steps, 90))
+    torch.cuda.synchronize()
 
     # per-kernel device time from hipEvents recorded on the launch stream inside the timed region
-    t_res, n_res = ctx.timing_get("residual")
     t_hes, n_hes = ctx.timing_get("hessian")
+    t_sol, n_sol = ctx.timing_get("solve")
     V_local = ctx.size()
     occ = ctx.factor_occupancy()     # occupied (voxel, frame) slots per voxel
     # algorithmic bytes per voxel: residual pass reads (W_occ+1)*80 + W*8 (the N column of every slot)
@@ -202,7 +211,8 @@ def main():
             "unit": "GB/s", "frac": res_gbs / HBM_PEAK_GBS, "traffic": None,
             "avg_launch_us": res_us, "launches": n_res, "algorithmic_bytes_per_launch": bytes_res,
             "other_kernels": {"k_hessian (K3, acc_evaluate2)": {"avg_launch_us": hes_us, "launches": n_hes, "algorithmic_GBps": hes_gbs,
-                                                                "algorithmic_bytes_per_launch": bytes_hes}},
+                                                                "algorithmic_bytes_per_launch": bytes_hes},
+                              "k_lm_solve (gauge + LDLT + retraction)": {"avg_launch_us": t_sol / max(n_sol, 1), "launches": n_sol}},
             "dominant_by_time": dominant}
 
     if rank == 0:

@@ -184,8 +184,11 @@ int vba_set_shard(vba_ctx *ctx, int rank, int n_ranks);
  * Measurement hooks (bench.py): average device time in microseconds of the named kernel family since
  * the last reset, from hipEvents recorded on the context's stream around each launch.             */
 int vba_timing_enable(vba_ctx *ctx, int on);
+/* Restrict the event bracketing to one kernel family (NULL / "" = all): two hipEventRecord calls per launch cost host
+ * time, so the headline timed region brackets only the kernel whose roofline is reported. */
+int vba_timing_select(vba_ctx *ctx, const char *name);
 int vba_timing_reset(vba_ctx *ctx);
-/* name in {"residual","hessian","reduce","insert","recut","margi"}; returns launches in *count. */
+/* name in {"residual","hessian","reduce","solve","insert","recut","margi"}; returns launches in *count. */
 int vba_timing_get(vba_ctx *ctx, const char *name, double *total_us, int *count);
 
 /* LM building blocks on device state (used by bench.py to time exactly K LM iterations, and by the

@@ -29,7 +29,7 @@ EXPORTS = [
     "vba_map_cut_voxel", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
-    "vba_timing_enable", "vba_timing_reset", "vba_timing_get",
+    "vba_timing_enable", "vba_timing_select", "vba_timing_reset", "vba_timing_get",
     "vba_lm_begin", "vba_lm_iterate", "vba_lm_end",
 ]
 
@@ -229,7 +229,11 @@ class Context:
         poses = _c(poses)
         self._chk(self.lib.vba_lm_begin(self.h, _p(poses), C.c_int(thd_num)))
 
-    def lm_iterate(self):
+    def lm_iterate(self, sync=True):
+        """One LM iteration (loop body voxel_map.hpp:441-494).  sync=False only enqueues the launches."""
+        if not sync:
+            self._chk(self.lib.vba_lm_iterate(self.h, None, None))
+            return None
         acc = C.c_int(0); stop = C.c_int(0)
         self._chk(self.lib.vba_lm_iterate(self.h, C.byref(acc), C.byref(stop)))
         return bool(acc.value), bool(stop.value)
@@ -295,6 +299,9 @@ class Context:
 
     def timing_enable(self, on=True):
         self.lib.vba_timing_enable(self.h, C.c_int(int(on)))
+
+    def timing_select(self, name=None):
+        self.lib.vba_timing_select(self.h, name.encode() if name else None)
 
     def timing_reset(self):
         self.lib.vba_timing_reset(self.h)

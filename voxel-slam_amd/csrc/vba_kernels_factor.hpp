@@ -131,8 +131,9 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 __global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__restrict__ poses, int head, int end,
-                                                 double *__restrict__ partial) {
+                                                 double *__restrict__ partial, const int *__restrict__ gate) {
   __shared__ double sp[VBA_MAX_WIN_DEV * 12];
+  if (gate && *gate == 0) return;   // device-side LM: the loop has stopped
   const int W = f.W;
   for (int t = threadIdx.x; t < W * 12; t += 64) sp[t] = poses[t];
   __syncthreads();
@@ -190,8 +191,10 @@ __global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__r
 
 // out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 16 outputs x 16 partial groups,
 // so ~nout/16 workgroups keep every CU busy on the (nb x nout) partial slab.
-__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nb, int nout, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nb, int nout, double *__restrict__ out,
+                                                        const int *__restrict__ gate) {
   __shared__ double s[256];
+  if (gate && *gate == 0) return;
   const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int o = blockIdx.x * 16 + j;
   double acc = 0.0;
@@ -208,8 +211,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 }
 
 // scalar version: out[0] = sum partial[0..nb)  (one workgroup, fixed tree)
-__global__ __launch_bounds__(256) void k_sum_scalar(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_sum_scalar(const double *__restrict__ partial, int nb, double *__restrict__ out,
+                                                   const int *__restrict__ gate) {
   __shared__ double s[4];
+  if (gate && *gate == 0) return;
   double acc = 0.0;
   for (int b = threadIdx.x; b < nb; b += 256) acc += partial[b];
   acc = wave_sum(acc);
@@ -247,9 +252,10 @@ struct HessCfg {
 
 template <int W>
 __global__ __launch_bounds__(HessCfg<W>::NT) void k_hessian(FactorView f, const double *__restrict__ poses, int head, int end,
-                                                            int ntiles, double *__restrict__ partial) {
+                                                            int ntiles, double *__restrict__ partial, const int *__restrict__ gate) {
   using C = HessCfg<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (gate && *gate == 0) return;   // device-side LM: rejected step -> the Hessian is not recomputed (VM:443)
   double *G = lds;                      // [NK][NCP]
   double *cK = G + (size_t)C::NK * C::NCP;  // [NK]
   double *sp = cK + C::NK;              // [W][12]

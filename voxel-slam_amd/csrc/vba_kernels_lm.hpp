@@ -1,0 +1,315 @@
+// Device-resident Levenberg-Marquardt loop of Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:422-497): the state
+// (poses, u, v, flags, H, g, trace) lives in HBM, so one LM iteration is a fixed chain of launches
+//   k_hessian -> k_reduce_partials -> [all-reduce] -> k_lm_solve -> k_residual -> k_sum_scalar -> [all-reduce] -> k_lm_update
+// with no host round trip; data-dependent control (is_calc_hess, the 1e-6 stop test) is carried by device flags that the
+// kernels test on entry.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vba {
+
+struct LmDev {
+  double x[VBA_MAX_WIN_DEV * 12];    // x_stats       (accepted poses)
+  double xt[VBA_MAX_WIN_DEV * 12];   // x_stats_temp  (trial poses)
+  double u, v, r1, r2, q1, resis_first;
+  int is_calc_hess, stop, iter, n_trace, all_accepted, last_accepted, max_trace, run_hess, run_res, pad;
+  double trace[5 * 64];              // rows [r1, r2, u, v, q1]
+};
+
+__device__ __forceinline__ void so3_exp_dev(const double *w, double *R) {   // tools.hpp:51-66
+  const double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (n >= 1e-11) {
+    const double a0 = w[0] / n, a1 = w[1] / n, a2 = w[2] / n;
+    const double s = sin(n), c1 = 1.0 - cos(n);
+    // K = hat(a), K^2 = a a^T - I
+    R[0] = 1.0 + c1 * (a0 * a0 - 1.0); R[1] = -s * a2 + c1 * a0 * a1;    R[2] = s * a1 + c1 * a0 * a2;
+    R[3] = s * a2 + c1 * a1 * a0;      R[4] = 1.0 + c1 * (a1 * a1 - 1.0); R[5] = -s * a0 + c1 * a1 * a2;
+    R[6] = -s * a1 + c1 * a2 * a0;     R[7] = s * a0 + c1 * a2 * a1;     R[8] = 1.0 + c1 * (a2 * a2 - 1.0);
+  } else {
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+  }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// `red` = the reduced [H | g | r] of the last Hessian pass.  It is never modified here: the gauge (first 6 rows/cols ->
+// identity, JacT.head(6) = 0, VM:452-455) and the damping u*diag are applied while the system is loaded, so a rejected
+// step re-reads the same H with a new u (VM:443) and `red[0..n^2)` doubles as *hess (VM:446).  With more than one rank
+// the hook all-reduces `red` in place on every iteration, so the valid copy is kept in `raw` (copy_raw != 0).
+//
+// Fast path, n = 6W <= 64: one wave owns the factorisation, lane i owns row i of P(H+uD)P^T.
+//   * [H|g|r] is staged into LDS once (256 threads), permuted/gauged/damped into the lane-strided image Lr[j][lane];
+//   * the factorisation is BLOCKED by pose (6 columns): the panel update is 6 independent dot products over the finished
+//     columns (one own-row read reused 6x, T read as three b128 from the transposed image TsT[j][k]), the 6x6 diagonal
+//     block is eliminated in registers with v_readlane broadcasts — no LDS round trip sits on the dependent chain;
+//   * all loops stay rolled (a fully unrolled register-resident variant was instruction-fetch bound: 40 us per launch).
+// Elimination order = Eigen's LDLT pivoting: largest |diagonal| of the *stored* matrix first (ldlt_inplace::unblocked),
+// realised as a rank computation (first index wins ties).  Measured ablation of the earlier unblocked LDS version:
+// factorisation 36 us, substitutions 5 us, prologue+epilogue 10 us of a 58 us launch (profiles/r01_solve_ablation.txt).
+template <int W>
+__global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw) {
+  constexpr int n = 6 * W;
+  static_assert(n <= 64, "single-wave solve");
+  __shared__ __attribute__((aligned(16))) double TsT[n][n + 2];   // TsT[j][k] = T[k][j] = d_j L[k][j]
+  __shared__ double Lr[n][64];                                   // Lr[j][lane] = L[lane][j]
+  __shared__ double Ls[n][n + 1];                                // Ls[k][i] = L[k][i]
+  __shared__ double dsh[n], gsh[n], hd[n], dxs[n];
+  __shared__ double Hs[n * n + n + 1];
+  __shared__ int ord[n];
+  const int tid = threadIdx.x;
+  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
+  const double u = s->u;
+  if (stop || (dbg & 8)) return;
+  {
+    const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
+    for (int t = tid; t < n * n + n + 1; t += 256) {
+      const double h = src[t];
+      Hs[t] = h;
+      if (copy_raw && calc) raw[t] = h;
+    }
+  }
+  double xr[12];                           // this lane's pose (retraction input), fetched while the factorisation runs
+  if (tid < W)
+#pragma unroll
+    for (int k = 0; k < 12; k++) xr[k] = s->x[12 * tid + k];
+  __syncthreads();
+  if (tid == 0 && calc) { const double r = Hs[n * n + n]; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
+  if (tid < n) {
+    const double h = tid < 6 ? 1.0 : Hs[tid * n + tid];                                                   // gauge VM:452-455
+    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : Hs[n * n + tid];
+    dsh[tid] = fabs(h + u * h);
+  }
+  __syncthreads();
+  if (tid < n) {
+    const double me = dsh[tid];
+    int rank = 0;
+#pragma unroll 12
+    for (int j = 0; j < n; j++) { const double o = dsh[j]; rank += (o > me || (o == me && j < tid)) ? 1 : 0; }
+    ord[rank] = tid;
+  }
+  __syncthreads();
+  for (int t = tid; t < n * 64; t += 256) {            // B = P (Hess + u D) P^T, lower part, lane-strided
+    const int j = t >> 6, i = t & 63;
+    double a = 0.0;
+    if (i < n && j <= i) {
+      const int pi = ord[i], pj = ord[j];
+      a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : Hs[pi * n + pj];
+      if (i == j) a += u * a;
+    }
+    Lr[j][i] = a;
+  }
+  __syncthreads();
+  if (tid >= 64 || (dbg & 4)) return;
+
+  for (int b = 0; b < ((dbg & 1) ? 0 : W); b++) {
+    const int k0 = 6 * b;
+    double sc[6], lc[6], tc[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) sc[c] = Lr[k0 + c][tid];
+    // (1) panel update with the finished columns j < k0
+#pragma unroll 6
+    for (int j = 0; j < k0; j++) {
+      const double lj = Lr[j][tid];
+      const double2 t0 = *reinterpret_cast<const double2 *>(&TsT[j][k0]);
+      const double2 t1 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 2]);
+      const double2 t2 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 4]);
+      sc[0] -= lj * t0.x; sc[1] -= lj * t0.y; sc[2] -= lj * t1.x; sc[3] -= lj * t1.y; sc[4] -= lj * t2.x; sc[5] -= lj * t2.y;
+    }
+    // (2) the 6x6 diagonal block, in registers
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const int k = k0 + c;
+#pragma unroll
+      for (int c2 = 0; c2 < c; c2++) sc[c] -= lc[c2] * readlane_f64(tc[c2], k);     // T[k][k0+c2] lives in lane k
+      const double dk = readlane_f64(sc[c], k);
+      const double l = (fabs(dk) > 0.0) ? sc[c] / dk : sc[c];
+      lc[c] = l; tc[c] = l * dk;
+      if (tid == k) dsh[k] = dk;
+    }
+    // (3) publish the block's columns
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const int k = k0 + c;
+      if (tid > k && tid < n) { Lr[k][tid] = lc[c]; TsT[k][tid] = tc[c]; Ls[tid][k] = lc[c]; }
+    }
+    __syncthreads();
+  }
+  // solve  P^T L^-T D^-1 L^-1 P (-g)
+  double y = tid < n ? -gsh[ord[tid]] : 0.0;
+#pragma unroll 12
+  for (int j = 0; j < ((dbg & 2) ? 0 : n); j++) {
+    const double lij = Lr[j][tid];
+    const double yj = readlane_f64(y, j);
+    if (tid > j && tid < n) y -= lij * yj;
+  }
+  {
+    const double dd = tid < n ? dsh[tid] : 1.0;
+    y = (fabs(dd) > 2.2250738585072014e-308) ? y / dd : 0.0;
+  }
+#pragma unroll 12
+  for (int j = ((dbg & 2) ? -1 : n - 1); j >= 0; j--) {
+    const double lji = tid < n ? Ls[j][tid] : 0.0;
+    const double yj = readlane_f64(y, j);
+    if (tid < j) y -= lji * yj;
+  }
+  if (tid < n) dxs[ord[tid]] = y;
+  __syncthreads();
+  if (tid < W) {                                                                                        // VM:460-464
+    double E[9];
+    so3_exp_dev(dxs + 6 * tid, E);
+    const double *R = xr;
+    double *Rt = s->xt + 12 * tid;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * E[c] + R[3 * r + 1] * E[3 + c] + R[3 * r + 2] * E[6 + c];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dxs[6 * tid + 3 + k];
+  }
+  double q = tid < n ? dxs[tid] * (u * hd[tid] * dxs[tid] - gsh[tid]) : 0.0;                              // VM:465
+  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+  if (tid == 0) s->q1 = 0.5 * q;
+}
+
+// Generic path (n = 6W up to 96): rows in LDS, one row per thread, two barriers per elimination step.
+__global__ __launch_bounds__(128) void k_lm_solve(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw, int W) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (s->stop) return;
+  const int n = 6 * W, ld = n + 2, tid = threadIdx.x, nt = blockDim.x;
+  double *L = lds, *T = L + (size_t)n * ld, *d = T + (size_t)n * ld, *y = d + n, *dx = y + n, *hd = dx + n, *gsh = hd + n;
+  int *ord = (int *)(gsh + n);
+  const int calc = s->is_calc_hess;
+  if (copy_raw && calc)
+    for (int t = tid; t < n * n + n + 1; t += nt) raw[t] = red[t];
+  __syncthreads();
+  const double *__restrict__ H = copy_raw ? raw : red;
+  if (tid == 0 && calc) { const double r = H[n * n + n]; s->r1 = r; if (s->iter == 0) s->resis_first = r; }
+  const double u = s->u;
+  if (tid < n) {
+    const double h = tid < 6 ? 1.0 : H[tid * n + tid];
+    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : H[n * n + tid];
+    d[tid] = fabs(h + u * h);
+  }
+  __syncthreads();
+  if (tid < n) {
+    const double me = d[tid];
+    int rank = 0;
+    for (int j = 0; j < n; j++) { const double o = d[j]; rank += (o > me || (o == me && j < tid)) ? 1 : 0; }
+    ord[rank] = tid;
+  }
+  __syncthreads();
+  for (int t = tid; t < n * n; t += nt) {
+    const int i = t / n, j = t % n;
+    if (j <= i) {
+      const int pi = ord[i], pj = ord[j];
+      double a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : H[pi * n + pj];
+      if (i == j) a += u * a;
+      L[i * ld + j] = a;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    double sacc = 0.0;
+    if (tid >= k && tid < n) {
+      sacc = L[tid * ld + k];
+      const double *li = L + (size_t)tid * ld, *tk = T + (size_t)k * ld;
+      int j = 0;
+      for (; j + 1 < k; j += 2) {
+        const double2 a = *reinterpret_cast<const double2 *>(li + j), b = *reinterpret_cast<const double2 *>(tk + j);
+        sacc -= a.x * b.x; sacc -= a.y * b.y;
+      }
+      if (j < k) sacc -= li[j] * tk[j];
+      if (tid == k) d[k] = sacc;
+    }
+    __syncthreads();
+    if (tid > k && tid < n) {
+      const double dk = d[k];
+      const double l = (fabs(dk) > 0.0) ? sacc / dk : sacc;
+      L[tid * ld + k] = l;
+      T[tid * ld + k] = l * dk;
+    }
+    __syncthreads();
+  }
+  if (tid < n) y[tid] = -gsh[ord[tid]];
+  __syncthreads();
+  for (int j = 0; j < n; j++) {
+    if (tid > j && tid < n) y[tid] -= L[tid * ld + j] * y[j];
+    __syncthreads();
+  }
+  if (tid < n) { const double dd = d[tid]; y[tid] = (fabs(dd) > 2.2250738585072014e-308) ? y[tid] / dd : 0.0; }
+  __syncthreads();
+  for (int j = n - 1; j >= 0; j--) {
+    if (tid < j) y[tid] -= L[j * ld + tid] * y[j];
+    __syncthreads();
+  }
+  if (tid < n) dx[ord[tid]] = y[tid];
+  __syncthreads();
+  if (tid < W) {
+    double E[9];
+    so3_exp_dev(dx + 6 * tid, E);
+    const double *R = s->x + 12 * tid;
+    double *Rt = s->xt + 12 * tid;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * E[c] + R[3 * r + 1] * E[3 + c] + R[3 * r + 2] * E[6 + c];
+    for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dx[6 * tid + 3 + k];
+  }
+  if (tid < n) y[tid] = dx[tid] * (u * hd[tid] * dx[tid] - gsh[tid]);
+  __syncthreads();
+  if (tid == 0) {
+    double q = 0.0;
+    for (int j = 0; j < n; j++) q += y[j];
+    s->q1 = 0.5 * q;
+  }
+}
+
+// Accept / reject bookkeeping of VM:467-494 (one thread).  r2_dev = the reduced residual of the trial poses.
+// nb > 0: r2 is first summed here from the residual pass' nb workgroup partials (single rank: saves one launch);
+// nb == 0: r2_dev already holds the (all-reduced) scalar.
+__global__ __launch_bounds__(64) void k_lm_update(LmDev *s, const double *__restrict__ r2_dev, int nb, int W) {
+  if (s->stop) return;
+  double r2;
+  if (nb > 0) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) acc += r2_dev[b];
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    r2 = acc;
+  } else {
+    r2 = *r2_dev;
+  }
+  if (threadIdx.x != 0) return;
+  const double r1 = s->r1, q1 = s->q1;
+  s->r2 = r2;
+  if (s->n_trace < s->max_trace) {
+    double *t = s->trace + 5 * s->n_trace;
+    t[0] = r1; t[1] = r2; t[2] = s->u; t[3] = s->v; t[4] = q1;
+    s->n_trace++;
+  }
+  double q = r1 - r2;
+  if (q > 0) {
+    for (int k = 0; k < 12 * W; k++) s->x[k] = s->xt[k];
+    const double one_three = 1.0 / 3;
+    q = q / q1;
+    s->v = 2;
+    q = 1 - pow(2 * q - 1, 3);
+    s->u *= (q < one_three ? one_three : q);
+    s->is_calc_hess = 1;
+    s->last_accepted = 1;
+  } else {
+    s->u = s->u * s->v;
+    s->v = 2 * s->v;
+    s->is_calc_hess = 0;
+    s->all_accepted = 0;       // is_converge = false   VM:489
+    s->last_accepted = 0;
+  }
+  s->iter++;
+  if (fabs((r1 - r2) / r1) < 1e-6) s->stop = 1;   // VM:492-493
+  s->run_res = s->stop ? 0 : 1;
+  s->run_hess = (s->is_calc_hess && !s->stop) ? 1 : 0;
+}
+
+}  // namespace vba

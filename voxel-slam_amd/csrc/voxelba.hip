@@ -6,6 +6,8 @@
 #define VBA_MAX_WIN_DEV VBA_MAX_WIN
 #include "vba_kernels_factor.hpp"
 #include "vba_kernels_map.hpp"
+#include "vba_kernels_lm.hpp"
+#include <cstddef>
 #include "vba_hostmath.hpp"
 
 #include <hip/hip_runtime.h>
@@ -59,19 +61,14 @@ struct vba_ctx {
 
   // timing
   bool timing = false;
+  std::string timing_only;        // when non-empty only this kernel family is bracketed by events
   std::map<std::string, std::vector<TimedSpan>> spans;
 
-  // LM state (lm_begin / lm_iterate / lm_end)
-  struct {
-    bool active = false;
-    int thd_num = 2;
-    double u = 0.01, v = 2;
-    bool is_calc_hess = true;
-    int iter = 0;
-    double residual1 = 0, residual2 = 0;
-    std::vector<double> x, x_temp, Hess, JacT, hess_saved;
-    double resis_first = 0;
-  } lm;
+  // device-resident LM state (lm_begin / lm_iterate / lm_end)
+  LmDev *d_lm = nullptr;
+  LmDev *h_lm = nullptr;          // pinned mirror
+  double *d_raw = nullptr;        // last valid all-reduced [H|g|r] (multi-rank only; single rank reads d_out in place)
+  struct { bool active = false; int thd_num = 2; } lm;
   std::vector<double> trace;
 
   MapStore map;
@@ -85,13 +82,14 @@ const int kMaxBlocksHess = 256;
 
 int nout_of(int W) { return 36 * W * W + 6 * W + 1; }
 
+static inline bool span_on(vba_ctx *c, const char *name) { return c->timing && (c->timing_only.empty() || c->timing_only == name); }
 void span_begin(vba_ctx *c, const char *name, TimedSpan &s) {
-  if (!c->timing) return;
+  if (!span_on(c, name)) return;
   hipEventCreate(&s.a); hipEventCreate(&s.b);
   hipEventRecord(s.a, c->stream);
 }
 void span_end(vba_ctx *c, const char *name, TimedSpan &s) {
-  if (!c->timing) return;
+  if (!span_on(c, name)) return;
   hipEventRecord(s.b, c->stream);
   c->spans[name].push_back(s);
 }
@@ -149,7 +147,7 @@ int upload_poses(vba_ctx *c, const double *poses) {
 }
 
 template <int W>
-int launch_hessian_t(vba_ctx *c, int head, int end, int *nblocks_out) {
+int launch_hessian_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out) {
   using C = HessCfg<W>;
   const int ntiles = (end - head + C::TV - 1) / C::TV;
   int nb = ntiles < kMaxBlocksHess ? ntiles : kMaxBlocksHess;
@@ -159,42 +157,40 @@ int launch_hessian_t(vba_ctx *c, int head, int end, int *nblocks_out) {
     hipFuncSetAttribute((const void *)k_hessian<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_hessian<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, c->d_poses, head, end, ntiles, c->d_partial);
+  hipLaunchKernelGGL(k_hessian<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate);
   *nblocks_out = nb;
   return VBA_OK;
 }
 
-int launch_hessian(vba_ctx *c, int head, int end, int *nb) {
+int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb) {
   switch (c->opt.win_size) {
-    case 2: return launch_hessian_t<2>(c, head, end, nb);
-    case 3: return launch_hessian_t<3>(c, head, end, nb);
-    case 4: return launch_hessian_t<4>(c, head, end, nb);
-    case 5: return launch_hessian_t<5>(c, head, end, nb);
-    case 6: return launch_hessian_t<6>(c, head, end, nb);
-    case 8: return launch_hessian_t<8>(c, head, end, nb);
-    case 10: return launch_hessian_t<10>(c, head, end, nb);
-    case 12: return launch_hessian_t<12>(c, head, end, nb);
-    case 16: return launch_hessian_t<16>(c, head, end, nb);
+    case 2: return launch_hessian_t<2>(c, pd, gate, head, end, nb);
+    case 3: return launch_hessian_t<3>(c, pd, gate, head, end, nb);
+    case 4: return launch_hessian_t<4>(c, pd, gate, head, end, nb);
+    case 5: return launch_hessian_t<5>(c, pd, gate, head, end, nb);
+    case 6: return launch_hessian_t<6>(c, pd, gate, head, end, nb);
+    case 8: return launch_hessian_t<8>(c, pd, gate, head, end, nb);
+    case 10: return launch_hessian_t<10>(c, pd, gate, head, end, nb);
+    case 12: return launch_hessian_t<12>(c, pd, gate, head, end, nb);
+    case 16: return launch_hessian_t<16>(c, pd, gate, head, end, nb);
     default: return VBA_ERR_UNSUPPORTED_WINDOW;
   }
 }
 
-// device: d_out[0..nout) = [H | g | r] over voxels [head,end) (+ all-reduce across ranks when configured)
-int eval_hessian_dev(vba_ctx *c, const double *poses, int head, int end) {
+// device passes on device-resident poses (gate == nullptr: unconditional)
+int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end) {
   const int W = c->opt.win_size, nout = nout_of(W);
-  int st = upload_poses(c, poses);
-  if (st) return st;
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)nout * sizeof(double), c->stream));
   } else {
     int nb = 0;
     TimedSpan s1{}, s2{};
     span_begin(c, "hessian", s1);
-    st = launch_hessian(c, head, end, &nb);
+    int st = launch_hessian(c, poses_dev, gate, head, end, &nb);
     if (st) return st;
     span_end(c, "hessian", s1);
     span_begin(c, "reduce", s2);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((nout + 15) / 16), dim3(256), 0, c->stream, c->d_partial, nb, nout, c->d_out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((nout + 15) / 16), dim3(256), 0, c->stream, c->d_partial, nb, nout, c->d_out, gate);
     span_end(c, "reduce", s2);
     HIPCHK(c, hipGetLastError());
   }
@@ -205,9 +201,7 @@ int eval_hessian_dev(vba_ctx *c, const double *poses, int head, int end) {
   return VBA_OK;
 }
 
-int eval_residual_dev(vba_ctx *c, const double *poses, int head, int end, double *d_scalar_out) {
-  int st = upload_poses(c, poses);
-  if (st) return st;
+int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, double *d_scalar_out) {
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(d_scalar_out, 0, sizeof(double), c->stream));
   } else {
@@ -215,10 +209,10 @@ int eval_residual_dev(vba_ctx *c, const double *poses, int head, int end, double
     if ((size_t)nb > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
     TimedSpan s1{}, s2{};
     span_begin(c, "residual", s1);
-    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, c->d_poses, head, end, c->d_partial);
+    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, poses_dev, head, end, c->d_partial, gate);
     span_end(c, "residual", s1);
     span_begin(c, "reduce", s2);
-    hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, c->stream, c->d_partial, nb, d_scalar_out);
+    hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, c->stream, c->d_partial, nb, d_scalar_out, gate);
     span_end(c, "reduce", s2);
     HIPCHK(c, hipGetLastError());
   }
@@ -227,6 +221,19 @@ int eval_residual_dev(vba_ctx *c, const double *poses, int head, int end, double
     if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
   }
   return VBA_OK;
+}
+
+// device: d_out[0..nout) = [H | g | r] over voxels [head,end) for host poses (+ all-reduce across ranks when configured)
+int eval_hessian_dev(vba_ctx *c, const double *poses, int head, int end) {
+  int st = upload_poses(c, poses);
+  if (st) return st;
+  return hessian_pass(c, c->d_poses, nullptr, head, end);
+}
+
+int eval_residual_dev(vba_ctx *c, const double *poses, int head, int end, double *d_scalar_out) {
+  int st = upload_poses(c, poses);
+  if (st) return st;
+  return residual_pass(c, c->d_poses, nullptr, head, end, d_scalar_out);
 }
 
 int ensure_partial(vba_ctx *c, size_t doubles) {
@@ -303,6 +310,13 @@ int vba_create(const vba_options *opt, vba_ctx **out) {
   if (hipMalloc((void **)&c->d_poses, (size_t)VBA_MAX_WIN * 12 * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&c->d_out, ((size_t)nout + 64) * sizeof(double)) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
   if (ensure_partial(c, (size_t)kMaxBlocksHess * nout) != VBA_OK || ensure_pin(c, 65536 + (size_t)nout + 1024) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
+  if (hipMalloc((void **)&c->d_lm, sizeof(LmDev)) != hipSuccess || hipMalloc((void **)&c->d_raw, ((size_t)nout + 64) * 8) != hipSuccess ||
+      hipHostMalloc((void **)&c->h_lm, sizeof(LmDev), hipHostMallocDefault) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
+  {
+    const int n = 6 * W, ld = n + 2;
+    const int lds = (int)(((size_t)2 * n * ld + 5 * n) * 8 + (size_t)n * 4 + 64);
+    hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
   if (opt->max_voxels && factor_reserve(c, (int)opt->max_voxels) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
   map_init(c->map, c->opt);
   *out = c;
@@ -318,6 +332,9 @@ void vba_destroy(vba_ctx *c) {
   for (double *q : p) if (q) hipFree(q);
   if (c->d_stage) hipFree(c->d_stage);
   if (c->h_pin) hipHostFree(c->h_pin);
+  if (c->d_lm) hipFree(c->d_lm);
+  if (c->d_raw) hipFree(c->d_raw);
+  if (c->h_lm) hipHostFree(c->h_lm);
   for (auto &kv : c->spans) for (auto &s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -419,106 +436,107 @@ int vba_factor_occupied_slots(vba_ctx *c, long long *slots) {
   return VBA_OK;
 }
 
-// ---------------------------------------------------------------- Lidar_BA_Optimizer (VM:342-498)
+// ---------------------------------------------------------------- Lidar_BA_Optimizer (VM:342-498), device-resident loop
 int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
-  const int W = c->opt.win_size, n = 6 * W;
-  auto &L = c->lm;
-  L.active = true; L.thd_num = thd_num; L.u = 0.01; L.v = 2; L.is_calc_hess = true; L.iter = 0;
-  L.x.assign(poses, poses + (size_t)W * 12);
-  L.x_temp = L.x;
-  L.Hess.assign((size_t)n * n, 0.0); L.JacT.assign(n, 0.0); L.hess_saved.assign((size_t)n * n, 0.0);
-  L.residual1 = L.residual2 = 0; L.resis_first = 0;
+  const int W = c->opt.win_size;
+  HIPCHK(c, hipStreamSynchronize(c->stream));     // the pinned mirror may still be in flight from a previous call
+  LmDev *h = c->h_lm;
+  std::memset(h, 0, sizeof(LmDev));
+  std::memcpy(h->x, poses, (size_t)W * 12 * sizeof(double));
+  std::memcpy(h->xt, poses, (size_t)W * 12 * sizeof(double));   // vector<IMUST> x_stats_temp = x_stats  VM:435
+  h->u = 0.01; h->v = 2;                                        // VM:427
+  h->is_calc_hess = 1; h->stop = 0; h->iter = 0; h->n_trace = 0; h->all_accepted = 1; h->last_accepted = 0; h->max_trace = 64;
+  h->run_hess = 1; h->run_res = 1;
+  { const char *e = getenv("VBA_DEBUG_SOLVE"); h->pad = e ? atoi(e) : 0; }   // timing ablation knob (0 in production)
+  HIPCHK(c, hipMemcpyAsync(c->d_lm, h, sizeof(LmDev), hipMemcpyHostToDevice, c->stream));
+  c->lm.active = true; c->lm.thd_num = thd_num;
   c->trace.clear();
   return VBA_OK;
 }
 
-// One trip through the loop body VM:441-494.
+// One trip through the loop body VM:441-494, enqueued without host synchronisation unless the caller asks for the flags.
 int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
-  auto &L = c->lm;
-  if (!L.active) return VBA_ERR_BAD_ARG;
-  const int W = c->opt.win_size, n = 6 * W, nout = nout_of(W), V = c->nvox;
-  int st;
-  if (L.is_calc_hess) {                                               // VM:443-447 (divide_thread over all voxels)
-    st = eval_hessian_dev(c, L.x.data(), 0, V);
-    if (st) return st;
-    std::vector<double> buf(nout);
-    st = fetch(c, c->d_out, nout, buf.data());
-    if (st) return st;
-    std::memcpy(L.Hess.data(), buf.data(), (size_t)n * n * sizeof(double));
-    std::memcpy(L.JacT.data(), buf.data() + (size_t)n * n, (size_t)n * sizeof(double));
-    L.residual1 = buf[(size_t)n * n + n];
-    L.hess_saved = L.Hess;                                            // *hess = Hess
+  if (!c->lm.active) return VBA_ERR_BAD_ARG;
+  const int W = c->opt.win_size, nout = nout_of(W), V = c->nvox;
+  if (V < c->lm.thd_num) return VBA_ERR_TOO_FEW_VOXELS;               // VM:399-403 (and g_size checks of VM:367)
+  char *base = reinterpret_cast<char *>(c->d_lm);
+  const double *x_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, x));
+  const double *xt_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, xt));
+  const int *run_hess = reinterpret_cast<const int *>(base + offsetof(LmDev, run_hess));
+  const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
+  int st = hessian_pass(c, x_dev, run_hess, 0, V);                    // divide_thread  VM:445 (skipped on device after a reject)
+  if (st) return st;
+  TimedSpan sp{};
+  span_begin(c, "solve", sp);
+  const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
+  switch (W) {
+    case 2: hipLaunchKernelGGL(k_lm_solve_w<2>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    case 3: hipLaunchKernelGGL(k_lm_solve_w<3>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    case 4: hipLaunchKernelGGL(k_lm_solve_w<4>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    case 5: hipLaunchKernelGGL(k_lm_solve_w<5>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    case 6: hipLaunchKernelGGL(k_lm_solve_w<6>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    case 8: hipLaunchKernelGGL(k_lm_solve_w<8>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    case 10: hipLaunchKernelGGL(k_lm_solve_w<10>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    default: {
+      const int n = 6 * W, ld = n + 2;
+      const size_t lds = ((size_t)2 * n * ld + 5 * n) * 8 + (size_t)n * 4 + 64;
+      hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(128), lds, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw, W);
+    }
   }
-  if (L.iter == 0) L.resis_first = L.residual1;                       // VM:449-450
-  double *H = L.Hess.data(), *g = L.JacT.data();
-  for (int r = 0; r < 6; r++) for (int k = 0; k < n; k++) { H[r * n + k] = 0; H[k * n + r] = 0; }   // VM:452-455
-  for (int r = 0; r < 6; r++) { H[r * n + r] = 1; g[r] = 0; }
-  std::vector<double> A(H, H + (size_t)n * n), rhs(n), dxi(n);
-  for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += L.u * H[(size_t)r * n + r]; rhs[r] = -g[r]; }     // VM:457-458
-  vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), n);
-  for (int j = 0; j < W; j++) {                                       // VM:460-464
-    double E[9];
-    vbh::so3_exp(&dxi[6 * j], E);
-    vbh::m3_mul(&L.x[12 * j], E, &L.x_temp[12 * j]);
-    for (int k = 0; k < 3; k++) L.x_temp[12 * j + 9 + k] = L.x[12 * j + 9 + k] + dxi[6 * j + 3 + k];
-  }
-  double q1 = 0;
-  for (int r = 0; r < n; r++) q1 += dxi[r] * (L.u * H[(size_t)r * n + r] * dxi[r] - g[r]);
-  q1 *= 0.5;                                                          // VM:465
-  if (V < L.thd_num) return VBA_ERR_TOO_FEW_VOXELS;                   // VM:399-403
+  span_end(c, "solve", sp);
   double *d_r = c->d_out + nout + 8;
-  st = eval_residual_dev(c, L.x_temp.data(), 0, V, d_r);              // VM:467
-  if (st) return st;
-  st = fetch(c, d_r, 1, &L.residual2);
-  if (st) return st;
-  double q = L.residual1 - L.residual2;
-  const double tr[5] = {L.residual1, L.residual2, L.u, L.v, q1};
-  c->trace.insert(c->trace.end(), tr, tr + 5);
-  bool acc = false;
-  if (q > 0) {                                                        // VM:473-483
-    L.x = L.x_temp;
-    const double one_three = 1.0 / 3;
-    q = q / q1;
-    L.v = 2;
-    q = 1 - std::pow(2 * q - 1, 3);
-    L.u *= (q < one_three ? one_three : q);
-    L.is_calc_hess = true;
-    acc = true;
-  } else {                                                            // VM:484-490
-    L.u = L.u * L.v;
-    L.v = 2 * L.v;
-    L.is_calc_hess = false;
+  if (c->allreduce && c->n_ranks > 1) {
+    st = residual_pass(c, xt_dev, run_res, 0, V, d_r);                // only_residual  VM:467 (+ scalar all-reduce)
+    if (st) return st;
+    hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, d_r, 0, W);
+  } else {
+    const int nb = (V + 63) / 64;
+    TimedSpan s1{};
+    span_begin(c, "residual", s1);
+    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, xt_dev, 0, V, c->d_partial, run_res);
+    span_end(c, "residual", s1);
+    hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_partial, nb, W);   // sums the partials itself
   }
-  L.iter++;
-  if (accepted) *accepted = acc ? 1 : 0;
-  if (stop) *stop = (std::fabs((L.residual1 - L.residual2) / L.residual1) < 1e-6) ? 1 : 0;   // VM:492-493
+  HIPCHK(c, hipGetLastError());
+  if (accepted || stop) {
+    HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (accepted) *accepted = c->h_lm->last_accepted;
+    if (stop) *stop = c->h_lm->stop;
+  }
   return VBA_OK;
 }
 
 int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
-  auto &L = c->lm;
-  if (!L.active) return VBA_ERR_BAD_ARG;
+  if (!c->lm.active) return VBA_ERR_BAD_ARG;
   const int W = c->opt.win_size, n = 6 * W;
-  if (poses) std::memcpy(poses, L.x.data(), (size_t)W * 12 * sizeof(double));
-  if (hess) std::memcpy(hess, L.hess_saved.data(), (size_t)n * n * sizeof(double));
-  if (resis2) { resis2[0] = L.resis_first; resis2[1] = L.residual2; }
-  L.active = false;
+  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
+  if (hess) {
+    int st = ensure_pin(c, 65536 + (size_t)n * n + 1024);
+    if (st) return st;
+    const double *src = (c->allreduce && c->n_ranks > 1) ? c->d_raw : c->d_out;    // *hess = Hess before gauge fixing (VM:446)
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, src, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const LmDev *h = c->h_lm;
+  if (poses) std::memcpy(poses, h->x, (size_t)W * 12 * sizeof(double));
+  if (hess) std::memcpy(hess, c->h_pin + 32768, (size_t)n * n * sizeof(double));
+  if (resis2) { resis2[0] = h->resis_first; resis2[1] = h->r2; }
+  c->trace.assign(h->trace, h->trace + 5 * h->n_trace);
+  c->lm.active = false;
   return VBA_OK;
 }
 
 int vba_lidar_ba_damping_iter(vba_ctx *c, double *poses, double *hess, double *resis2, int max_iter, int thd_num, int *is_converge) {
   int st = vba_lm_begin(c, poses, thd_num);
   if (st) return st;
-  bool conv = true;
-  for (int i = 0; i < max_iter; i++) {
-    int acc = 0, stop = 0;
-    st = vba_lm_iterate(c, &acc, &stop);
+  for (int i = 0; i < max_iter; i++) {           // the 1e-6 break (VM:492) is a device flag: later launches return at once
+    st = vba_lm_iterate(c, nullptr, nullptr);
     if (st) { c->lm.active = false; return st; }
-    if (!acc) conv = false;                                           // VM:489
-    if (stop) break;
   }
-  if (is_converge) *is_converge = conv ? 1 : 0;
-  return vba_lm_end(c, poses, hess, resis2);
+  st = vba_lm_end(c, poses, hess, resis2);
+  if (is_converge) *is_converge = c->h_lm->all_accepted;
+  return st;
 }
 
 int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
@@ -686,6 +704,7 @@ int vba_set_shard(vba_ctx *c, int rank, int n_ranks) {
 
 // ---------------------------------------------------------------- timing
 int vba_timing_enable(vba_ctx *c, int on) { c->timing = on != 0; return VBA_OK; }
+int vba_timing_select(vba_ctx *c, const char *name) { c->timing_only = name ? name : ""; return VBA_OK; }
 int vba_timing_reset(vba_ctx *c) {
   hipStreamSynchronize(c->stream);
   for (auto &kv : c->spans) for (auto &s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
