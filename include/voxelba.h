@@ -193,9 +193,10 @@ int vba_timing_get(vba_ctx *ctx, const char *name, double *total_us, int *count)
 
 /* LM building blocks on device state (used by bench.py to time exactly K LM iterations, and by the
  * damping_iter entry points themselves): begin loads the poses, iterate runs one trip through the
- * loop body VM:441-494 / VM:643-710, end copies the refined poses back. */
+ * loop body VM:441-494 / VM:643-710, end copies the refined poses back (all-NULL outputs: no synchronisation). */
 int vba_lm_begin(vba_ctx *ctx, const double *poses, int thd_num);
-int vba_lm_iterate(vba_ctx *ctx, int *accepted, int *stop);
+int vba_lm_refresh_eigen(vba_ctx *ctx); /* device-side residual pass at the begin poses (re-creates eig/pcr_add state) */
+int vba_lm_iterate(vba_ctx *ctx, int *accepted, int *stop); /* NULL, NULL: enqueue only (no host synchronisation) */
 int vba_lm_end(vba_ctx *ctx, double *poses, double *hess, double *resis2);
 
 #ifdef __cplusplus

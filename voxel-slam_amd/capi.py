@@ -30,7 +30,7 @@ EXPORTS = [
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_reset", "vba_timing_get",
-    "vba_lm_begin", "vba_lm_iterate", "vba_lm_end",
+    "vba_lm_begin", "vba_lm_refresh_eigen", "vba_lm_iterate", "vba_lm_end",
 ]
 
 
@@ -238,7 +238,13 @@ class Context:
         self._chk(self.lib.vba_lm_iterate(self.h, C.byref(acc), C.byref(stop)))
         return bool(acc.value), bool(stop.value)
 
-    def lm_end(self):
+    def lm_refresh_eigen(self):
+        self._chk(self.lib.vba_lm_refresh_eigen(self.h))
+
+    def lm_end(self, fetch=True):
+        if not fetch:
+            self._chk(self.lib.vba_lm_end(self.h, None, None, None))
+            return None
         n = 6 * self.W
         poses = np.empty((self.W, 12)); H = np.empty((n, n)); resis = np.zeros(2)
         self._chk(self.lib.vba_lm_end(self.h, _p(poses), _p(H), _p(resis)))

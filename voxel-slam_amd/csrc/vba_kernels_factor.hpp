@@ -189,6 +189,74 @@ __global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__r
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// K4, latency-restructured (template on the window size so that every loop unrolls):
+//   round 1: the N column of all W slots + the fixed cluster + coe (independent loads, one round trip);
+//   round 2: the 9 remaining scalars of every OCCUPIED slot, all issued before the first use (lanes whose slot is empty
+//            are masked off, so empty slots still cost 8 B, not 80 B);
+//   then transforms, Jacobi eigen-solve, write-back.  The generic kernel above pays one dependent round trip per frame.
+// Poses are read through uniform (scalar) loads: the frame index is a compile-time constant after unrolling.
+template <int W>
+__global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *__restrict__ poses, int head, int end,
+                                                   double *__restrict__ partial, const int *__restrict__ gate) {
+  if (gate && *gate == 0) return;
+  const int v = head + blockIdx.x * 64 + threadIdx.x;
+  const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
+  double r = 0.0;
+  if (v < end) {
+    double nn[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) nn[i] = f.cl[9 * fs + (size_t)i * vs + v];
+    double P00 = f.fix[0 * vs + v], P01 = f.fix[1 * vs + v], P02 = f.fix[2 * vs + v];
+    double P11 = f.fix[3 * vs + v], P12 = f.fix[4 * vs + v], P22 = f.fix[5 * vs + v];
+    double s0 = f.fix[6 * vs + v], s1 = f.fix[7 * vs + v], s2 = f.fix[8 * vs + v];
+    double N = f.fix[9 * vs + v];
+    const double coe = f.coe[v];
+    double c[W][9];
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      const bool occ = nn[i] != 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) c[i][k] = occ ? f.cl[(size_t)k * fs + (size_t)i * vs + v] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      const double n = nn[i];
+      if (n != 0.0) {
+        const double pxx = c[i][0], pxy = c[i][1], pxz = c[i][2], pyy = c[i][3], pyz = c[i][4], pzz = c[i][5];
+        const double vx = c[i][6], vy = c[i][7], vz = c[i][8];
+        const double *R = poses + 12 * i;
+        const double tx = R[9], ty = R[10], tz = R[11];
+        const double rv0 = R[0] * vx + R[1] * vy + R[2] * vz;
+        const double rv1 = R[3] * vx + R[4] * vy + R[5] * vz;
+        const double rv2 = R[6] * vx + R[7] * vy + R[8] * vz;
+        const double m00 = R[0] * pxx + R[1] * pxy + R[2] * pxz, m01 = R[0] * pxy + R[1] * pyy + R[2] * pyz, m02 = R[0] * pxz + R[1] * pyz + R[2] * pzz;
+        const double m10 = R[3] * pxx + R[4] * pxy + R[5] * pxz, m11 = R[3] * pxy + R[4] * pyy + R[5] * pyz, m12 = R[3] * pxz + R[4] * pyz + R[5] * pzz;
+        const double m20 = R[6] * pxx + R[7] * pxy + R[8] * pxz, m21 = R[6] * pxy + R[7] * pyy + R[8] * pyz, m22 = R[6] * pxz + R[7] * pyz + R[8] * pzz;
+        P00 += (m00 * R[0] + m01 * R[1] + m02 * R[2]) + 2.0 * rv0 * tx + n * tx * tx;
+        P01 += (m10 * R[0] + m11 * R[1] + m12 * R[2]) + (rv1 * tx + rv0 * ty) + n * ty * tx;
+        P02 += (m20 * R[0] + m21 * R[1] + m22 * R[2]) + (rv2 * tx + rv0 * tz) + n * tz * tx;
+        P11 += (m10 * R[3] + m11 * R[4] + m12 * R[5]) + 2.0 * rv1 * ty + n * ty * ty;
+        P12 += (m20 * R[3] + m21 * R[4] + m22 * R[5]) + (rv2 * ty + rv1 * tz) + n * tz * ty;
+        P22 += (m20 * R[6] + m21 * R[7] + m22 * R[8]) + 2.0 * rv2 * tz + n * tz * tz;
+        s0 += rv0 + n * tx; s1 += rv1 + n * ty; s2 += rv2 + n * tz;
+        N += n;
+      }
+    }
+    const double b0 = s0 / N, b1 = s1 / N, b2 = s2 / N;
+    double w0, w1, w2, V[9];
+    eig3_sym_dev(P00 / N - b0 * b0, P01 / N - b1 * b0, P02 / N - b2 * b0, P11 / N - b1 * b1, P12 / N - b2 * b1, P22 / N - b2 * b2,
+                 w0, w1, w2, V);
+    f.eigval[0 * vs + v] = w0; f.eigval[1 * vs + v] = w1; f.eigval[2 * vs + v] = w2;
+#pragma unroll
+    for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + v] = V[k];
+    f.pcr[0 * vs + v] = P00; f.pcr[1 * vs + v] = P01; f.pcr[2 * vs + v] = P02; f.pcr[3 * vs + v] = P11; f.pcr[4 * vs + v] = P12;
+    f.pcr[5 * vs + v] = P22; f.pcr[6 * vs + v] = s0; f.pcr[7 * vs + v] = s1; f.pcr[8 * vs + v] = s2; f.pcr[9 * vs + v] = N;
+    r = coe * w0;
+  }
+  r = wave_sum(r);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 // out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 16 outputs x 16 partial groups,
 // so ~nout/16 workgroups keep every CU busy on the (nb x nout) partial slab.
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nb, int nout, double *__restrict__ out,
@@ -228,117 +296,154 @@ __global__ __launch_bounds__(256) void k_sum_scalar(const double *__restrict__ p
 // Per voxel  H_v = coe * ( G_v^T C_v G_v + blockdiag_i(E_{v,i}) )   with G_v (3 x 6W) rows
 //   g_{.,1}, g_{.,2}  (g_{i,m} = Auk_i^T u_m, VM:228-232,240)  and  h_. = [vi x Ri^T uk ; n_i uk],
 //   C_v = diag(2/(l0-l1), 2/(l0-l2), -2/NN^2)                                  (VM:198-201, 264-268)
-// and E_{v,i} the diagonal-block terms not covered by the rank-3 form (VM:242-248).  This identity is checked
-// against the oracle's literal per-pair accumulation in tests/ (and SURVEY.md §3.4).
-// Workgroup = 32 voxels x W frames (one thread per (voxel, frame) slot) per tile:
-//   phase A: slot threads build their 3 rows x 6 columns of G in LDS, accumulate E / gradient privately;
-//   phase B: the workgroup contracts the 96-row tile G^T C G into register patches (4x4, upper triangle).
-// Output: one partial [ (6W)^2 | 6W | 1 ] per workgroup, reduced by k_reduce_partials.
+// and E_{v,i} the diagonal-block terms not covered by the rank-3 form (VM:242-248; its -0.5 hat(jjt) term cancels the
+// antisymmetric part of the rot-rot block exactly, so only the symmetric part is formed).  The identity is checked against
+// the oracle's literal per-pair accumulation in tests/ (and SURVEY.md 3.4).
+// Workgroup = TV voxels x W frames (one thread per (voxel, frame) slot) per tile:
+//   phase A: slot threads build their 3 rows x 6 columns of G in LDS, accumulate E / gradient / residual privately;
+//   phase B: the workgroup contracts the tile G^T C G on the matrix cores.
+// Output per workgroup ("tile layout", NOUT2 doubles): [NU upper-triangle 16x16 accumulator tiles in MFMA register order
+// | E 21 per frame | g 6 per frame | r]; k_reduce_partials sums the workgroups, tl_fetch() maps it back to H(row, col).
+// Structure chosen from MI355X measurements of the first version (VALU contraction, 5-wave tiles, full 60x60 LDS image in
+// the epilogue: 34.5 us per pass at V = 1.8e4, in-kernel stamps in profiles/r01_k3_stamps.txt):
+//   * phase A issues ALL of a slot's loads in one batch (no dependent second round trip on N != 0) and the loads of the
+//     NEXT tile are issued before the current tile's contraction, so they fly under phase B;
+//   * phase B is the dense contraction H += G^T C G on the matrix cores: v_mfma_f64_16x16x4_f64, each wave owns
+//     ceil(NU / waves) of the NU upper-triangle 16x16 tiles of the (6W)^2 output (W = 10: 10 tiles over 5 waves);
+//     LDS image G[k][GS] with GS = 16 (mod 32) doubles, so the 4 rows x 16 columns a wave reads per operand are
+//     bank-conflict free (rows k, k+1 land in opposite halves of the 64 banks);
+//   * the epilogue writes the accumulator tiles straight into the LDS H image (no zero fill).
+// f64 MFMA fragment layout (cdna_hip_programming.md, "f64 MFMA does NOT use these maps"):
+//   A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[row = (l >> 4) + 4 r][col = l & 15], r = 0..3.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int hess2_tv(int W) {   // voxels per tile: ~256 / W slot threads = exactly 4 waves, multiple of 8, K-split divisible
+  return W == 2 ? 128 : W == 3 ? 80 : W == 4 ? 64 : W == 5 ? 48 : W == 6 ? 40 : W == 8 ? 32 : W == 10 ? 24 : 16;
+}
+constexpr int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
+
 template <int W>
-struct HessCfg {
-  static constexpr int TV = 32;                            // voxels per tile
-  static constexpr int NT = ((TV * W + 63) / 64) * 64;     // threads
-  static constexpr int NC = 6 * W;                         // columns
-  static constexpr int NP = (NC + 3) / 4;                  // 4-wide patches per dimension
-  static constexpr int NCP = NP * 4;                       // padded columns
-  static constexpr int NPATCH = NP * (NP + 1) / 2;         // upper-triangle patches
-  static constexpr int KSPLIT = (NT / NPATCH) < 1 ? 1 : ((NT / NPATCH) > 4 ? 4 : (NT / NPATCH));
-  static constexpr int NK = 3 * TV;                        // rows per tile (96)
-  static constexpr int NOUT = NC * NC + NC + 1;
-  static constexpr size_t LDS_DOUBLES = (size_t)NK * NCP + NK + W * 12 + 8;
-  static constexpr size_t LDS_EPI = (size_t)NC * NC + NC + 8;
-  static constexpr size_t LDS_BYTES = (LDS_DOUBLES > LDS_EPI ? LDS_DOUBLES : LDS_EPI) * sizeof(double);
+struct HessCfg2 {
+  static constexpr int TV = hess2_tv(W);
+  static constexpr int NT = 256;                         // 4 waves: one per SIMD (5 waves measured 2x slower per tile)
+  static constexpr int NC = 6 * W;
+  static constexpr int NT16 = (NC + 15) / 16;
+  static constexpr int NCP = 16 * NT16;
+  static constexpr int GS = (NCP % 32 == 16) ? NCP : NCP + 16;
+  static constexpr int NK = 3 * TV;
+  static constexpr int NWV = NT / 64;
+  static constexpr int NU = NT16 * (NT16 + 1) / 2;       // upper-triangle 16x16 tiles
+  static constexpr int KS = NWV / gcd_i(NU, NWV);        // K-splits so that NU*KS units divide evenly over the waves
+  static constexpr int UPW = NU * KS / NWV;              // (tile, k-split) units per wave
+  static constexpr int KSTEPS = NK / 4 / KS;             // MFMAs per unit
+  static constexpr int NOUT = NC * NC + NC + 1;           // full layout [H | g | r]
+  static constexpr int EB = NU * 256;                     // tile layout: offset of the per-frame E blocks
+  static constexpr int GB = EB + 21 * W;                  //              offset of the gradient
+  static constexpr int RB = GB + 6 * W;                   //              offset of the residual
+  static constexpr int NOUT2 = RB + 1;
+  static constexpr int NG8 = NT / 8;
+  static_assert(TV * W <= NT && TV % 8 == 0 && (NK / 4) % KS == 0 && (NU * KS) % NWV == 0, "tile shape");
+  static constexpr size_t LDS_MAIN = (size_t)NK * GS + NK + W * 12 + 8;
+  static constexpr size_t LDS_EPI = (size_t)(KS > 1 ? NU * 256 : 0) + (size_t)28 * NG8 + 8;
+  static constexpr size_t LDS_BYTES = (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) * sizeof(double);
+};
+
+struct SlotLoad {   // everything one (voxel, frame) slot thread reads from HBM
+  double n, c[9], coe, l0, l1, l2, NN, vs0, vs1, vs2, U[9];
+  bool valid;
 };
 
 template <int W>
-__global__ __launch_bounds__(HessCfg<W>::NT) void k_hessian(FactorView f, const double *__restrict__ poses, int head, int end,
-                                                            int ntiles, double *__restrict__ partial, const int *__restrict__ gate) {
-  using C = HessCfg<W>;
+__device__ __forceinline__ void slot_load(const FactorView &f, int v, int fi, int end, SlotLoad &q) {
+  const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
+  q.valid = v < end;
+  if (q.valid) {
+    const double *cp = f.cl + (size_t)fi * vs + v;
+    q.n = cp[9 * fs];
+#pragma unroll
+    for (int k = 0; k < 9; k++) q.c[k] = cp[(size_t)k * fs];
+    q.coe = f.coe[v];
+    q.l0 = f.eigval[v]; q.l1 = f.eigval[vs + v]; q.l2 = f.eigval[2 * vs + v];
+    q.NN = f.pcr[9 * vs + v]; q.vs0 = f.pcr[6 * vs + v]; q.vs1 = f.pcr[7 * vs + v]; q.vs2 = f.pcr[8 * vs + v];
+#pragma unroll
+    for (int k = 0; k < 9; k++) q.U[k] = f.eigvec[(size_t)k * vs + v];
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, const double *__restrict__ poses, int head, int end,
+                                                             int ntiles, double *__restrict__ partial, const int *__restrict__ gate,
+                                                             long long *__restrict__ stamps) {
+  using C = HessCfg2<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (gate && *gate == 0) return;   // device-side LM: rejected step -> the Hessian is not recomputed (VM:443)
-  double *G = lds;                      // [NK][NCP]
-  double *cK = G + (size_t)C::NK * C::NCP;  // [NK]
-  double *sp = cK + C::NK;              // [W][12]
-  const int tid = threadIdx.x;
-  const size_t vs = (size_t)f.vs;
-  const size_t fs = (size_t)W * vs;
+  if (gate && *gate == 0) return;
+  // diagnostic stamps (stamps == nullptr in production): per workgroup [start, prologue, A0, B0, A1, B1, ..., reduce, end]
+#define VBA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+  VBA_STAMP(0);
+  double *G = lds;                            // [NK][GS]
+  double *cK = G + (size_t)C::NK * C::GS;     // [NK]
+  double *sp = cK + C::NK;                    // [W][12]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   for (int t = tid; t < W * 12; t += C::NT) sp[t] = poses[t];
-  for (int t = tid; t < C::NK * C::NCP; t += C::NT) G[t] = 0.0;   // padded columns stay zero for the whole kernel
-  __syncthreads();
+  for (int t = tid; t < C::NK * (C::GS - C::NC); t += C::NT)       // padded columns stay zero for the whole kernel
+    G[(size_t)(t / (C::GS - C::NC)) * C::GS + C::NC + t % (C::GS - C::NC)] = 0.0;
 
-  const int vl = tid & 31, fi = tid >> 5;      // slot = (voxel-in-tile, frame)
+  const int vl = tid % C::TV, fi = tid / C::TV;
   const bool slot_thread = fi < W;
-  // phase-B role
-  const int patch = tid % C::NPATCH, ks = tid / C::NPATCH;
-  const bool syrk_thread = ks < C::KSPLIT;
-  int pa = 0, pb = 0;
-  {
-    int p = patch, row = 0;
-    while (p >= C::NP - row) { p -= C::NP - row; row++; }
-    pa = row; pb = row + p;
-  }
-  double acc[4][4];
+  v4f64 acc[C::UPW];
 #pragma unroll
-  for (int e = 0; e < 4; e++)
-#pragma unroll
-    for (int g = 0; g < 4; g++) acc[e][g] = 0.0;
+  for (int t = 0; t < C::UPW; t++) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
   double Err[6] = {0, 0, 0, 0, 0, 0}, Ert[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Ett[6] = {0, 0, 0, 0, 0, 0};
   double gj[6] = {0, 0, 0, 0, 0, 0};
   double rres = 0.0;
 
+  SlotLoad nx;
+  nx.valid = false;
+  if (slot_thread && (int)blockIdx.x < ntiles) slot_load<W>(f, head + blockIdx.x * C::TV + vl, fi, end, nx);
+  __syncthreads();
+  VBA_STAMP(1);
+  int stamp_i = 2;
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---------------- phase A
+    // ---------------- phase A (registers of this tile were loaded one iteration ago)
     if (slot_thread) {
-      const int v = head + tile * C::TV + vl;
+      const SlotLoad q = nx;
       double g1[6] = {0, 0, 0, 0, 0, 0}, g2[6] = {0, 0, 0, 0, 0, 0}, hh[6] = {0, 0, 0, 0, 0, 0};
       double ck1 = 0.0, ck2 = 0.0, ck3 = 0.0;
-      if (v < end) {
-        const double coe = f.coe[v];
-        const double l0 = f.eigval[v], l1 = f.eigval[vs + v], l2 = f.eigval[2 * vs + v];
-        const double NN = f.pcr[9 * vs + v];
-        const double c1 = 2.0 / (l0 - l1), c2 = 2.0 / (l0 - l2);      // VM:201
+      if (q.valid) {
+        const double coe = q.coe, l0 = q.l0, NN = q.NN;
+        const double c1 = 2.0 / (l0 - q.l1), c2 = 2.0 / (l0 - q.l2);      // VM:201
         ck1 = coe * c1; ck2 = coe * c2; ck3 = coe * (-2.0 / NN / NN);
-        if (fi == 0) rres += coe * l0;                                // VM:275
-        const double *cp = f.cl + (size_t)fi * vs + v;
-        const double n = cp[9 * fs];
+        if (fi == 0) rres += coe * l0;                                    // VM:275
+        const double n = q.n;
         if (n != 0.0) {
-          const double pxx = cp[0], pxy = cp[fs], pxz = cp[2 * fs], pyy = cp[3 * fs], pyz = cp[4 * fs], pzz = cp[5 * fs];
-          const double vx = cp[6 * fs], vy = cp[7 * fs], vz = cp[8 * fs];
-          const double u00 = f.eigvec[0 * vs + v], u01 = f.eigvec[1 * vs + v], u02 = f.eigvec[2 * vs + v];
-          const double u10 = f.eigvec[3 * vs + v], u11 = f.eigvec[4 * vs + v], u12 = f.eigvec[5 * vs + v];
-          const double u20 = f.eigvec[6 * vs + v], u21 = f.eigvec[7 * vs + v], u22 = f.eigvec[8 * vs + v];
+          const double pxx = q.c[0], pxy = q.c[1], pxz = q.c[2], pyy = q.c[3], pyz = q.c[4], pzz = q.c[5];
+          const double vx = q.c[6], vy = q.c[7], vz = q.c[8];
+          const double u00 = q.U[0], u01 = q.U[1], u02 = q.U[2], u10 = q.U[3], u11 = q.U[4], u12 = q.U[5], u20 = q.U[6], u21 = q.U[7], u22 = q.U[8];
           const double inn = 1.0 / NN;
-          const double bx = f.pcr[6 * vs + v] * inn, by = f.pcr[7 * vs + v] * inn, bz = f.pcr[8 * vs + v] * inn;  // vBar (VM:190)
+          const double bx = q.vs0 * inn, by = q.vs1 * inn, bz = q.vs2 * inn;                                      // vBar (VM:190)
           const double *R = sp + 12 * fi;
-          // eigenvectors uk=u0 (col 0), u1, u2
           const double k0 = u00, k1 = u10, k2 = u20;
-          // a_m = R^T u_m
           const double a00 = R[0] * k0 + R[3] * k1 + R[6] * k2, a01 = R[1] * k0 + R[4] * k1 + R[7] * k2, a02 = R[2] * k0 + R[5] * k1 + R[8] * k2;
           const double a10 = R[0] * u01 + R[3] * u11 + R[6] * u21, a11 = R[1] * u01 + R[4] * u11 + R[7] * u21, a12 = R[2] * u01 + R[5] * u11 + R[8] * u21;
           const double a20 = R[0] * u02 + R[3] * u12 + R[6] * u22, a21 = R[1] * u02 + R[4] * u12 + R[7] * u22, a22 = R[2] * u02 + R[5] * u12 + R[8] * u22;
-          // ti_v = p - vBar ; s_m = u_m . ti_v                                       (VM:224-225)
-          const double tx = R[9] - bx, ty = R[10] - by, tz = R[11] - bz;
+          const double tx = R[9] - bx, ty = R[10] - by, tz = R[11] - bz;                                           // VM:224
           const double s0 = k0 * tx + k1 * ty + k2 * tz, s1 = u01 * tx + u11 * ty + u21 * tz, s2 = u02 * tx + u12 * ty + u22 * tz;
-          // P a_m
           const double pa00 = pxx * a00 + pxy * a01 + pxz * a02, pa01 = pxy * a00 + pyy * a01 + pyz * a02, pa02 = pxz * a00 + pyz * a01 + pzz * a02;
           const double pa10 = pxx * a10 + pxy * a11 + pxz * a12, pa11 = pxy * a10 + pyy * a11 + pyz * a12, pa12 = pxz * a10 + pyz * a11 + pzz * a12;
           const double pa20 = pxx * a20 + pxy * a21 + pxz * a22, pa21 = pxy * a20 + pyy * a21 + pyz * a22, pa22 = pxz * a20 + pyz * a21 + pzz * a22;
-          // w = P a0 + s0 v   (combo1 = hat(w), VM:228) ; combo2 = R v + n ti_v (VM:229)
-          const double wx = pa00 + s0 * vx, wy = pa01 + s0 * vy, wz = pa02 + s0 * vz;
-          const double c2x = R[0] * vx + R[1] * vy + R[2] * vz + n * tx;
+          const double wx = pa00 + s0 * vx, wy = pa01 + s0 * vy, wz = pa02 + s0 * vz;                              // combo1 = hat(w) VM:228
+          const double c2x = R[0] * vx + R[1] * vy + R[2] * vz + n * tx;                                           // combo2 VM:229
           const double c2y = R[3] * vx + R[4] * vy + R[5] * vz + n * ty;
           const double c2z = R[6] * vx + R[7] * vy + R[8] * vz + n * tz;
-          // q = v x a0  (viRiTuk, VM:221)
-          const double qx = vy * a02 - vz * a01, qy = vz * a00 - vx * a02, qz = vx * a01 - vy * a00;
-          // g_rot,m = ( -a0 x (P a_m + s_m v) + w x a_m ) / NN ; g_tr,m = ( uk (c2.u_m) + (c2.uk) u_m ) / NN
+          const double qx = vy * a02 - vz * a01, qy = vz * a00 - vx * a02, qz = vx * a01 - vy * a00;              // viRiTuk VM:221
           const double d0 = c2x * k0 + c2y * k1 + c2z * k2;
           const double d1 = c2x * u01 + c2y * u11 + c2z * u21;
           const double d2 = c2x * u02 + c2y * u12 + c2z * u22;
-          // m = 0 (gradient, VM:235): g_rot,0 = 2 (w x a0)/NN, g_tr,0 = 2 d0 uk / NN
           const double j0 = 2.0 * (wy * a02 - wz * a01) * inn, j1 = 2.0 * (wz * a00 - wx * a02) * inn, j2 = 2.0 * (wx * a01 - wy * a00) * inn;
           const double j3 = 2.0 * d0 * k0 * inn, j4 = 2.0 * d0 * k1 * inn, j5 = 2.0 * d0 * k2 * inn;
-          gj[0] += coe * j0; gj[1] += coe * j1; gj[2] += coe * j2; gj[3] += coe * j3; gj[4] += coe * j4; gj[5] += coe * j5;
+          gj[0] += coe * j0; gj[1] += coe * j1; gj[2] += coe * j2; gj[3] += coe * j3; gj[4] += coe * j4; gj[5] += coe * j5;   // VM:235-236
           {
             const double bx1 = pa10 + s1 * vx, by1 = pa11 + s1 * vy, bz1 = pa12 + s1 * vz;
             g1[0] = (-(a01 * bz1 - a02 * by1) + (wy * a12 - wz * a11)) * inn;
@@ -352,14 +457,10 @@ __global__ __launch_bounds__(HessCfg<W>::NT) void k_hessian(FactorView f, const 
             g2[3] = (k0 * d2 + d0 * u02) * inn; g2[4] = (k1 * d2 + d0 * u12) * inn; g2[5] = (k2 * d2 + d0 * u22) * inn;
           }
           hh[0] = qx; hh[1] = qy; hh[2] = qz; hh[3] = n * k0; hh[4] = n * k1; hh[5] = n * k2;
-          // E_rr = (2/NN) [ sym(a0 w^T) - (w.a0) I - hat(a0) P hat(a0) ]   (symmetric part of VM:242; the -0.5 hat(jjt)
-          //        term cancels the antisymmetric part exactly)
           const double wa = wx * a00 + wy * a01 + wz * a02;
-          // T = hat(a0) P  (rows: a0 x P[:,c] columnwise -> T[r][c] = (a0 x Pc)_r with Pc = column c of P)
           const double t00 = a01 * pxz - a02 * pxy, t10 = a02 * pxx - a00 * pxz, t20 = a00 * pxy - a01 * pxx;
           const double t01 = a01 * pyz - a02 * pyy, t11 = a02 * pxy - a00 * pyz, t21 = a00 * pyy - a01 * pxy;
           const double t02 = a01 * pzz - a02 * pyz, t12 = a02 * pxz - a00 * pzz, t22 = a00 * pyz - a01 * pxz;
-          // S = T hat(a0):  S[r][c] = sum_k T[r][k] hat(a0)[k][c];  hat(a0) = [0 -a02 a01; a02 0 -a00; -a01 a00 0]
           const double S00 = t01 * a02 - t02 * a01, S01 = -t00 * a02 + t02 * a00, S02 = t00 * a01 - t01 * a00;
           const double S11 = -t10 * a02 + t12 * a00, S12 = t10 * a01 - t11 * a00;
           const double S22 = t20 * a01 - t21 * a00;
@@ -370,7 +471,6 @@ __global__ __launch_bounds__(HessCfg<W>::NT) void k_hessian(FactorView f, const 
           Err[3] += e2 * (a01 * wy - wa - S11);
           Err[4] += e2 * (0.5 * (a01 * wz + wy * a02) - S12);
           Err[5] += e2 * (a02 * wz - wa - S22);
-          // E_rt = (2/NN) q uk^T (VM:239,244 without the -ni/NN part that lives in the rank-3 form) ; E_tt = (2 n/NN) uk uk^T
           Ert[0] += e2 * qx * k0; Ert[1] += e2 * qx * k1; Ert[2] += e2 * qx * k2;
           Ert[3] += e2 * qy * k0; Ert[4] += e2 * qy * k1; Ert[5] += e2 * qy * k2;
           Ert[6] += e2 * qz * k0; Ert[7] += e2 * qz * k1; Ert[8] += e2 * qz * k2;
@@ -378,85 +478,150 @@ __global__ __launch_bounds__(HessCfg<W>::NT) void k_hessian(FactorView f, const 
           Ett[0] += e3 * k0 * k0; Ett[1] += e3 * k0 * k1; Ett[2] += e3 * k0 * k2; Ett[3] += e3 * k1 * k1; Ett[4] += e3 * k1 * k2; Ett[5] += e3 * k2 * k2;
         }
       }
-      double *g = G + (size_t)(3 * vl) * C::NCP + 6 * fi;
+      double *g = G + (size_t)(3 * vl) * C::GS + 6 * fi;
 #pragma unroll
-      for (int d = 0; d < 6; d++) { g[d] = g1[d]; g[C::NCP + d] = g2[d]; g[2 * C::NCP + d] = hh[d]; }
+      for (int d = 0; d < 6; d++) { g[d] = g1[d]; g[C::GS + d] = g2[d]; g[2 * C::GS + d] = hh[d]; }
       if (fi == 0) { cK[3 * vl] = ck1; cK[3 * vl + 1] = ck2; cK[3 * vl + 2] = ck3; }
+      // the next tile's loads fly under this tile's contraction
+      const int nt = tile + gridDim.x;
+      nx.valid = false;
+      if (nt < ntiles) slot_load<W>(f, head + nt * C::TV + vl, fi, end, nx);
     }
     __syncthreads();
-    // ---------------- phase B: acc += sum_k cK[k] G[k][4pa+e] G[k][4pb+g]
-    if (syrk_thread) {
-      const int k0 = ks * (C::NK / C::KSPLIT), k1 = (ks == C::KSPLIT - 1) ? C::NK : k0 + C::NK / C::KSPLIT;
-      const double *ga = G + 4 * pa, *gb = G + 4 * pb;
-      for (int k = k0; k < k1; k++) {
-        const double ck = cK[k];
-        const double2 x0 = *reinterpret_cast<const double2 *>(ga + (size_t)k * C::NCP);
-        const double2 x1 = *reinterpret_cast<const double2 *>(ga + (size_t)k * C::NCP + 2);
-        const double2 y0 = *reinterpret_cast<const double2 *>(gb + (size_t)k * C::NCP);
-        const double2 y1 = *reinterpret_cast<const double2 *>(gb + (size_t)k * C::NCP + 2);
-        const double a[4] = {x0.x * ck, x0.y * ck, x1.x * ck, x1.y * ck};
-        const double b[4] = {y0.x, y0.y, y1.x, y1.y};
+    if (stamp_i < 12) { VBA_STAMP(stamp_i); stamp_i++; }
+    // ---------------- phase B: MFMA contraction of the tile's NK rows; unit = (16x16 tile, k-split)
+    {
+      const int kr = lane >> 4, cl = lane & 15;
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+      for (int t = 0; t < C::UPW; t++) {
+        const int unit = wv * C::UPW + t;
+        const int u = unit % C::NU, ksp = unit / C::NU;
+        int p = u, ta = 0;
+        while (p >= C::NT16 - ta) { p -= C::NT16 - ta; ta++; }
+        const int tb = ta + p;
+        const int kb = ksp * C::KSTEPS * 4;
+        const double *ga = G + (size_t)(kb + kr) * C::GS + 16 * ta + cl;
+        const double *gb = G + (size_t)(kb + kr) * C::GS + 16 * tb + cl;
+        const double *ck = cK + kb + kr;
+        v4f64 a4 = acc[t];
 #pragma unroll
-          for (int g = 0; g < 4; g++) acc[e][g] += a[e] * b[g];
+        for (int k = 0; k < C::KSTEPS * 4; k += 4) {
+          const double av = ga[(size_t)k * C::GS] * ck[k];
+          const double bv = gb[(size_t)k * C::GS];
+          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a4, 0, 0, 0);
+        }
+        acc[t] = a4;
       }
     }
     __syncthreads();
+    if (stamp_i < 12) { VBA_STAMP(stamp_i); stamp_i++; }
   }
+  VBA_STAMP(12);
 
-  // ---------------- epilogue: assemble the workgroup's partial in LDS, then store
-  double *Hs = lds;                          // [NC][NC]
-  double *gs = Hs + (size_t)C::NC * C::NC;   // [NC]
-  double *rs = gs + C::NC;                   // [1]
-  for (int t = tid; t < C::NC * C::NC + C::NC + 1; t += C::NT) Hs[t] = 0.0;
-  __syncthreads();
-  for (int s = 0; s < C::KSPLIT; s++) {
-    if (syrk_thread && ks == s) {
+  // ---------------- epilogue: accumulator tiles go to HBM in register order (coalesced 512 B per wave store)
+  double *out = partial + (size_t)blockIdx.x * C::NOUT2;
+  double *Tb = lds;                                   // [NU][256] staging to combine k-splits
+  double *Eb = Tb + (C::KS > 1 ? C::NU * 256 : 0);    // [28][NG8]
+  if (C::KS > 1) {
 #pragma unroll
-      for (int e = 0; e < 4; e++)
+    for (int t = 0; t < C::UPW; t++) {
+      const int unit = wv * C::UPW + t;
+      if (unit / C::NU != 0) {
+        const int u = unit % C::NU;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int r = 4 * pa + e, c = 4 * pb + g;
-          if (r < C::NC && c < C::NC && r <= c) Hs[r * C::NC + c] += acc[e][g];
+        for (int r = 0; r < 4; r++) {
+          if (unit / C::NU == 1) Tb[u * 256 + r * 64 + lane] = acc[t][r];
         }
+      }
     }
-    __syncthreads();
-  }
-  // wave-level reduction of the private E / gradient / residual over the 32 voxel lanes of each frame
+    for (int ksp = 2; ksp < C::KS; ksp++) {
+      __syncthreads();
 #pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) {
+      for (int t = 0; t < C::UPW; t++) {
+        const int unit = wv * C::UPW + t;
+        if (unit / C::NU == ksp) {
+          const int u = unit % C::NU;
+#pragma unroll
+          for (int r = 0; r < 4; r++) Tb[u * 256 + r * 64 + lane] += acc[t][r];
+        }
+      }
+    }
+  }
+  // E / gradient / residual: 8-lane groups never straddle a frame (TV % 8 == 0)
+#pragma unroll
+  for (int m = 4; m >= 1; m >>= 1) {
 #pragma unroll
     for (int k = 0; k < 6; k++) { Err[k] += __shfl_xor(Err[k], m, 64); Ett[k] += __shfl_xor(Ett[k], m, 64); gj[k] += __shfl_xor(gj[k], m, 64); }
 #pragma unroll
     for (int k = 0; k < 9; k++) Ert[k] += __shfl_xor(Ert[k], m, 64);
     rres += __shfl_xor(rres, m, 64);
   }
-  if (slot_thread && vl == 0) {
-    const int o = 6 * fi;
-    // rot-rot (upper incl. diagonal)
-    Hs[(o + 0) * C::NC + o + 0] += Err[0]; Hs[(o + 0) * C::NC + o + 1] += Err[1]; Hs[(o + 0) * C::NC + o + 2] += Err[2];
-    Hs[(o + 1) * C::NC + o + 1] += Err[3]; Hs[(o + 1) * C::NC + o + 2] += Err[4]; Hs[(o + 2) * C::NC + o + 2] += Err[5];
-    // rot-trans
+  if ((tid & 7) == 0) {
+    const int g8 = tid >> 3;
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+    for (int k = 0; k < 6; k++) { Eb[(size_t)k * C::NG8 + g8] = Err[k]; Eb[(size_t)(15 + k) * C::NG8 + g8] = Ett[k]; Eb[(size_t)(21 + k) * C::NG8 + g8] = gj[k]; }
 #pragma unroll
-      for (int c = 0; c < 3; c++) Hs[(o + r) * C::NC + o + 3 + c] += Ert[3 * r + c];
-    // trans-trans
-    Hs[(o + 3) * C::NC + o + 3] += Ett[0]; Hs[(o + 3) * C::NC + o + 4] += Ett[1]; Hs[(o + 3) * C::NC + o + 5] += Ett[2];
-    Hs[(o + 4) * C::NC + o + 4] += Ett[3]; Hs[(o + 4) * C::NC + o + 5] += Ett[4]; Hs[(o + 5) * C::NC + o + 5] += Ett[5];
-#pragma unroll
-    for (int k = 0; k < 6; k++) gs[o + k] = gj[k];
-    if (fi == 0) rs[0] = rres;
+    for (int k = 0; k < 9; k++) Eb[(size_t)(6 + k) * C::NG8 + g8] = Ert[k];
+    Eb[(size_t)27 * C::NG8 + g8] = rres;
   }
   __syncthreads();
-  // mirror upper -> lower (VM:279-281) and store
-  double *out = partial + (size_t)blockIdx.x * C::NOUT;
-  for (int t = tid; t < C::NC * C::NC; t += C::NT) {
-    const int r = t / C::NC, c = t % C::NC;
-    out[t] = (r <= c) ? Hs[t] : Hs[c * C::NC + r];
+  VBA_STAMP(13);
+#pragma unroll
+  for (int t = 0; t < C::UPW; t++) {
+    const int unit = wv * C::UPW + t;
+    if (unit / C::NU == 0) {
+      const int u = unit % C::NU;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double val = acc[t][r];
+        if (C::KS > 1) val += Tb[u * 256 + r * 64 + lane];
+        out[u * 256 + r * 64 + lane] = val;
+      }
+    }
   }
-  for (int t = tid; t < C::NC + 1; t += C::NT) out[C::NC * C::NC + t] = gs[t];
+  for (int t = tid; t < 28 * W; t += C::NT) {
+    const int k = t % 28, fr = t / 28;
+    double sum = 0.0;
+#pragma unroll
+    for (int g = 0; g < C::TV / 8; g++) sum += Eb[(size_t)k * C::NG8 + fr * (C::TV / 8) + g];
+    if (k < 21) out[C::EB + 21 * fr + k] = sum;
+    else if (k < 27) out[C::GB + 6 * fr + (k - 21)] = sum;
+    else if (fr == 0) out[C::RB] = sum;
+  }
+  VBA_STAMP(14);
+#undef VBA_STAMP
+}
+
+// Tile layout -> H(row, col) of the (6W x 6W) Hessian (symmetric: the upper triangle is stored, VM:279-281 mirrors it).
+template <int W>
+__device__ __forceinline__ double tl_fetch(const double *__restrict__ red, int row, int col) {
+  using C = HessCfg2<W>;
+  if (row > col) { const int t = row; row = col; col = t; }
+  const int ta = row >> 4, tb = col >> 4;
+  const int u = ta * C::NT16 - ta * (ta - 1) / 2 + (tb - ta);
+  const int rt = row & 15, ct = col & 15;
+  double val = red[u * 256 + (rt >> 2) * 64 + (rt & 3) * 16 + ct];
+  const int fr = row / 6;
+  if (col / 6 == fr) {
+    const int a = row - 6 * fr, b = col - 6 * fr;
+    int idx;
+    if (b < 3) idx = a * 3 - a * (a - 1) / 2 + (b - a);
+    else if (a < 3) idx = 6 + 3 * a + (b - 3);
+    else { const int a2 = a - 3, b2 = b - 3; idx = 15 + a2 * 3 - a2 * (a2 - 1) / 2 + (b2 - a2); }
+    val += red[C::EB + 21 * fr + idx];
+  }
+  return val;
+}
+
+// Tile layout -> full layout [H | g | r] for host consumers (acc_evaluate2, *hess of the optimizers).
+template <int W>
+__global__ void k_tiles_to_full(const double *__restrict__ red, double *__restrict__ full) {
+  using C = HessCfg2<W>;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < C::NOUT; t += gridDim.x * blockDim.x) {
+    if (t < C::NC * C::NC) full[t] = tl_fetch<W>(red, t / C::NC, t % C::NC);
+    else if (t < C::NC * C::NC + C::NC) full[t] = red[C::GB + (t - C::NC * C::NC)];
+    else full[t] = red[C::RB];
+  }
 }
 
 }  // namespace vba

@@ -14,6 +14,7 @@ struct LmDev {
   double u, v, r1, r2, q1, resis_first;
   int is_calc_hess, stop, iter, n_trace, all_accepted, last_accepted, max_trace, run_hess, run_res, pad;
   double trace[5 * 64];              // rows [r1, r2, u, v, q1]
+  long long stamps[64];              // diagnostic (VBA_DEBUG_SOLVE bit 16)
 };
 
 __device__ __forceinline__ void so3_exp_dev(const double *w, double *R) {   // tools.hpp:51-66
@@ -59,29 +60,23 @@ __global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__re
   __shared__ double Lr[n][64];                                   // Lr[j][lane] = L[lane][j]
   __shared__ double Ls[n][n + 1];                                // Ls[k][i] = L[k][i]
   __shared__ double dsh[n], gsh[n], hd[n], dxs[n];
-  __shared__ double Hs[n * n + n + 1];
   __shared__ int ord[n];
+  using C2 = HessCfg2<W>;
   const int tid = threadIdx.x;
   const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
   const double u = s->u;
   if (stop || (dbg & 8)) return;
-  {
-    const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
-    for (int t = tid; t < n * n + n + 1; t += 256) {
-      const double h = src[t];
-      Hs[t] = h;
-      if (copy_raw && calc) raw[t] = h;
-    }
-  }
+  const double *__restrict__ src = (copy_raw && !calc) ? raw : red;       // tile layout (vba_kernels_factor.hpp)
+  if (copy_raw && calc)
+    for (int t = tid; t < C2::NOUT2; t += 256) raw[t] = src[t];
   double xr[12];                           // this lane's pose (retraction input), fetched while the factorisation runs
   if (tid < W)
 #pragma unroll
     for (int k = 0; k < 12; k++) xr[k] = s->x[12 * tid + k];
-  __syncthreads();
-  if (tid == 0 && calc) { const double r = Hs[n * n + n]; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
+  if (tid == 0 && calc) { const double r = src[C2::RB]; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
   if (tid < n) {
-    const double h = tid < 6 ? 1.0 : Hs[tid * n + tid];                                                   // gauge VM:452-455
-    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : Hs[n * n + tid];
+    const double h = tid < 6 ? 1.0 : tl_fetch<W>(src, tid, tid);                                          // gauge VM:452-455
+    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : src[C2::GB + tid];
     dsh[tid] = fabs(h + u * h);
   }
   __syncthreads();
@@ -93,33 +88,39 @@ __global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__re
     ord[rank] = tid;
   }
   __syncthreads();
-  for (int t = tid; t < n * 64; t += 256) {            // B = P (Hess + u D) P^T, lower part, lane-strided
+  for (int t = tid; t < n * 64; t += 256) {            // B = P (Hess + u D) P^T, lower part, lane-strided, gathered from HBM/L2
     const int j = t >> 6, i = t & 63;
     double a = 0.0;
     if (i < n && j <= i) {
       const int pi = ord[i], pj = ord[j];
-      a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : Hs[pi * n + pj];
+      a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : tl_fetch<W>(src, pi, pj);
       if (i == j) a += u * a;
     }
     Lr[j][i] = a;
   }
   __syncthreads();
   if (tid >= 64 || (dbg & 4)) return;
+  const bool stamp = (dbg & 16) && tid == 0;
+  if (stamp) { s->stamps[0] = wall_clock64(); s->stamps[50] = clock64(); }
 
   for (int b = 0; b < ((dbg & 1) ? 0 : W); b++) {
     const int k0 = 6 * b;
     double sc[6], lc[6], tc[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) sc[c] = Lr[k0 + c][tid];
-    // (1) panel update with the finished columns j < k0
-#pragma unroll 6
-    for (int j = 0; j < k0; j++) {
-      const double lj = Lr[j][tid];
-      const double2 t0 = *reinterpret_cast<const double2 *>(&TsT[j][k0]);
-      const double2 t1 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 2]);
-      const double2 t2 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 4]);
-      sc[0] -= lj * t0.x; sc[1] -= lj * t0.y; sc[2] -= lj * t1.x; sc[3] -= lj * t1.y; sc[4] -= lj * t2.x; sc[5] -= lj * t2.y;
+    // (1) panel update with the finished columns j < k0 (k0 is a multiple of 6: the unrolled body has no remainder)
+    for (int jb = 0; jb < b; jb++) {
+#pragma unroll
+      for (int jj = 0; jj < 6; jj++) {
+        const int j = 6 * jb + jj;
+        const double lj = Lr[j][tid];
+        const double2 t0 = *reinterpret_cast<const double2 *>(&TsT[j][k0]);
+        const double2 t1 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 2]);
+        const double2 t2 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 4]);
+        sc[0] -= lj * t0.x; sc[1] -= lj * t0.y; sc[2] -= lj * t1.x; sc[3] -= lj * t1.y; sc[4] -= lj * t2.x; sc[5] -= lj * t2.y;
+      }
     }
+    if (stamp) s->stamps[1 + 3 * b] = clock64();
     // (2) the 6x6 diagonal block, in registers
 #pragma unroll
     for (int c = 0; c < 6; c++) {
@@ -127,10 +128,15 @@ __global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__re
 #pragma unroll
       for (int c2 = 0; c2 < c; c2++) sc[c] -= lc[c2] * readlane_f64(tc[c2], k);     // T[k][k0+c2] lives in lane k
       const double dk = readlane_f64(sc[c], k);
-      const double l = (fabs(dk) > 0.0) ? sc[c] / dk : sc[c];
+      // 1/dk by v_rcp_f64 + two Newton steps (the dependent chain of the factorisation runs through this pivot)
+      double inv = __builtin_amdgcn_rcp(dk);
+      inv = fma(fma(-dk, inv, 1.0), inv, inv);
+      inv = fma(fma(-dk, inv, 1.0), inv, inv);
+      const double l = (fabs(dk) > 0.0) ? sc[c] * inv : sc[c];
       lc[c] = l; tc[c] = l * dk;
       if (tid == k) dsh[k] = dk;
     }
+    if (stamp) s->stamps[2 + 3 * b] = clock64();
     // (3) publish the block's columns
 #pragma unroll
     for (int c = 0; c < 6; c++) {
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__re
       if (tid > k && tid < n) { Lr[k][tid] = lc[c]; TsT[k][tid] = tc[c]; Ls[tid][k] = lc[c]; }
     }
     __syncthreads();
+    if (stamp) s->stamps[3 + 3 * b] = clock64();
   }
   // solve  P^T L^-T D^-1 L^-1 P (-g)
   double y = tid < n ? -gsh[ord[tid]] : 0.0;
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__re
   }
   if (tid < n) dxs[ord[tid]] = y;
   __syncthreads();
+  if (stamp) { s->stamps[40] = wall_clock64(); s->stamps[51] = clock64(); }
   if (tid < W) {                                                                                        // VM:460-464
     double E[9];
     so3_exp_dev(dxs + 6 * tid, E);
@@ -176,23 +184,26 @@ __global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__re
   if (tid == 0) s->q1 = 0.5 * q;
 }
 
-// Generic path (n = 6W up to 96): rows in LDS, one row per thread, two barriers per elimination step.
-__global__ __launch_bounds__(128) void k_lm_solve(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw, int W) {
+// Generic path (n = 6W up to 96, i.e. W = 12, 16): rows in LDS, one row per thread, two barriers per elimination step.
+template <int W>
+__global__ __launch_bounds__(128) void k_lm_solve_g(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (s->stop) return;
-  const int n = 6 * W, ld = n + 2, tid = threadIdx.x, nt = blockDim.x;
+  using C2 = HessCfg2<W>;
+  constexpr int n = 6 * W, ld = n + 2;
+  const int tid = threadIdx.x, nt = blockDim.x;
   double *L = lds, *T = L + (size_t)n * ld, *d = T + (size_t)n * ld, *y = d + n, *dx = y + n, *hd = dx + n, *gsh = hd + n;
   int *ord = (int *)(gsh + n);
   const int calc = s->is_calc_hess;
   if (copy_raw && calc)
-    for (int t = tid; t < n * n + n + 1; t += nt) raw[t] = red[t];
+    for (int t = tid; t < C2::NOUT2; t += nt) raw[t] = red[t];
   __syncthreads();
-  const double *__restrict__ H = copy_raw ? raw : red;
-  if (tid == 0 && calc) { const double r = H[n * n + n]; s->r1 = r; if (s->iter == 0) s->resis_first = r; }
+  const double *__restrict__ H = copy_raw ? raw : red;      // tile layout
+  if (tid == 0 && calc) { const double r = H[C2::RB]; s->r1 = r; if (s->iter == 0) s->resis_first = r; }
   const double u = s->u;
   if (tid < n) {
-    const double h = tid < 6 ? 1.0 : H[tid * n + tid];
-    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : H[n * n + tid];
+    const double h = tid < 6 ? 1.0 : tl_fetch<W>(H, tid, tid);
+    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : H[C2::GB + tid];
     d[tid] = fabs(h + u * h);
   }
   __syncthreads();
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(128) void k_lm_solve(LmDev *s, const double *__rest
     const int i = t / n, j = t % n;
     if (j <= i) {
       const int pi = ord[i], pj = ord[j];
-      double a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : H[pi * n + pj];
+      double a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : tl_fetch<W>(H, pi, pj);
       if (i == j) a += u * a;
       L[i * ld + j] = a;
     }
@@ -269,47 +280,58 @@ __global__ __launch_bounds__(128) void k_lm_solve(LmDev *s, const double *__rest
 
 // Accept / reject bookkeeping of VM:467-494 (one thread).  r2_dev = the reduced residual of the trial poses.
 // nb > 0: r2 is first summed here from the residual pass' nb workgroup partials (single rank: saves one launch);
-// nb == 0: r2_dev already holds the (all-reduced) scalar.
+// nb == 0: r2_dev already holds the (all-reduced) scalar.  One wave; every lane takes the (uniform) decision so that the
+// pose copy x <- x_temp is a parallel copy and no dependent chain of single-lane global accesses remains.
 __global__ __launch_bounds__(64) void k_lm_update(LmDev *s, const double *__restrict__ r2_dev, int nb, int W) {
-  if (s->stop) return;
+  const int stop = s->stop, ntr = s->n_trace, mtr = s->max_trace, it = s->iter;
+  const double r1 = s->r1, q1 = s->q1, u0 = s->u, v0 = s->v;
+  const int lane = threadIdx.x;
+  double xt0 = 0.0, xt1 = 0.0, xt2 = 0.0;                 // up to 192 pose scalars = 3 per lane
+  if (lane < 12 * W) xt0 = s->xt[lane];
+  if (lane + 64 < 12 * W) xt1 = s->xt[lane + 64];
+  if (lane + 128 < 12 * W) xt2 = s->xt[lane + 128];
+  if (stop) return;
   double r2;
   if (nb > 0) {
     double acc = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) acc += r2_dev[b];
+    for (int b = lane; b < nb; b += 64) acc += r2_dev[b];
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
     r2 = acc;
   } else {
     r2 = *r2_dev;
   }
-  if (threadIdx.x != 0) return;
-  const double r1 = s->r1, q1 = s->q1;
-  s->r2 = r2;
-  if (s->n_trace < s->max_trace) {
-    double *t = s->trace + 5 * s->n_trace;
-    t[0] = r1; t[1] = r2; t[2] = s->u; t[3] = s->v; t[4] = q1;
-    s->n_trace++;
-  }
-  double q = r1 - r2;
-  if (q > 0) {
-    for (int k = 0; k < 12 * W; k++) s->x[k] = s->xt[k];
+  double q = r1 - r2, u = u0, v = v0;
+  const bool accept = q > 0;
+  if (accept) {                                             // VM:473-483
+    if (lane < 12 * W) s->x[lane] = xt0;
+    if (lane + 64 < 12 * W) s->x[lane + 64] = xt1;
+    if (lane + 128 < 12 * W) s->x[lane + 128] = xt2;
     const double one_three = 1.0 / 3;
     q = q / q1;
-    s->v = 2;
-    q = 1 - pow(2 * q - 1, 3);
-    s->u *= (q < one_three ? one_three : q);
-    s->is_calc_hess = 1;
-    s->last_accepted = 1;
-  } else {
-    s->u = s->u * s->v;
-    s->v = 2 * s->v;
-    s->is_calc_hess = 0;
-    s->all_accepted = 0;       // is_converge = false   VM:489
-    s->last_accepted = 0;
+    v = 2;
+    const double t = 2 * q - 1;
+    q = 1 - t * t * t;                                      // pow(2q-1, 3)
+    u *= (q < one_three ? one_three : q);
+  } else {                                                  // VM:484-490
+    u = u * v;
+    v = 2 * v;
   }
-  s->iter++;
-  if (fabs((r1 - r2) / r1) < 1e-6) s->stop = 1;   // VM:492-493
-  s->run_res = s->stop ? 0 : 1;
-  s->run_hess = (s->is_calc_hess && !s->stop) ? 1 : 0;
+  if (lane != 0) return;
+  s->r2 = r2;
+  if (ntr < mtr) {
+    double *t = s->trace + 5 * ntr;
+    t[0] = r1; t[1] = r2; t[2] = u0; t[3] = v0; t[4] = q1;
+    s->n_trace = ntr + 1;
+  }
+  s->u = u; s->v = v;
+  s->is_calc_hess = accept ? 1 : 0;
+  s->last_accepted = accept ? 1 : 0;
+  if (!accept) s->all_accepted = 0;                         // is_converge = false   VM:489
+  s->iter = it + 1;
+  const int nstop = (fabs((r1 - r2) / r1) < 1e-6) ? 1 : 0;  // VM:492-493
+  s->stop = nstop;
+  s->run_res = nstop ? 0 : 1;
+  s->run_hess = (accept && !nstop) ? 1 : 0;
 }
 
 }  // namespace vba

@@ -48,7 +48,9 @@ struct vba_ctx {
   double *d_poses = nullptr;     // [W][12]
   double *d_partial = nullptr;   // workgroup partials
   size_t partial_doubles = 0;
-  double *d_out = nullptr;       // reduced [H | g | r] (+ scalar residual slot at the end)
+  double *d_out = nullptr;       // reduced Hessian pass, tile layout (vba_kernels_factor.hpp)
+  double *d_full = nullptr;      // the same in full layout [H | g | r] for host consumers
+  double *d_scal = nullptr;      // reduced residual scalar
   double *h_pin = nullptr;       // pinned host staging
   size_t pin_doubles = 0;
   void *d_stage = nullptr;       // AoS upload staging
@@ -66,7 +68,11 @@ struct vba_ctx {
 
   // device-resident LM state (lm_begin / lm_iterate / lm_end)
   LmDev *d_lm = nullptr;
-  LmDev *h_lm = nullptr;          // pinned mirror
+  LmDev *h_lm = nullptr;          // pinned mirror (download side)
+  static const int kLmRing = 8;
+  LmDev *h_lm_up[kLmRing] = {nullptr};   // pinned upload ring: lm_begin never has to drain the stream
+  hipEvent_t lm_up_ev[kLmRing] = {nullptr};
+  int lm_up_next = 0;
   double *d_raw = nullptr;        // last valid all-reduced [H|g|r] (multi-rank only; single rank reads d_out in place)
   struct { bool active = false; int thd_num = 2; } lm;
   std::vector<double> trace;
@@ -80,7 +86,11 @@ namespace {
 
 const int kMaxBlocksHess = 256;
 
-int nout_of(int W) { return 36 * W * W + 6 * W + 1; }
+int nout_of(int W) { return 36 * W * W + 6 * W + 1; }   // full layout [H | g | r]
+int nout_tl(int W) {                                      // tile layout produced by k_hessian2 (HessCfg2<W>::NOUT2)
+  const int nt16 = (6 * W + 15) / 16;
+  return nt16 * (nt16 + 1) / 2 * 256 + 27 * W + 1;
+}
 
 static inline bool span_on(vba_ctx *c, const char *name) { return c->timing && (c->timing_only.empty() || c->timing_only == name); }
 void span_begin(vba_ctx *c, const char *name, TimedSpan &s) {
@@ -147,39 +157,71 @@ int upload_poses(vba_ctx *c, const double *poses) {
 }
 
 template <int W>
-int launch_hessian_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out) {
-  using C = HessCfg<W>;
+int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out) {
+  using C = HessCfg2<W>;
   const int ntiles = (end - head + C::TV - 1) / C::TV;
   int nb = ntiles < kMaxBlocksHess ? ntiles : kMaxBlocksHess;
   if (nb < 1) nb = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void *)k_hessian<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    hipFuncSetAttribute((const void *)k_hessian2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_hessian<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate);
+  long long *stamps = nullptr;
+  static const bool want_stamps = getenv("VBA_K3_STAMPS") != nullptr;     // diagnostic build switch, off in production
+  if (want_stamps) {
+    static long long *d_st = nullptr;
+    if (!d_st) hipMalloc((void **)&d_st, (size_t)kMaxBlocksHess * 16 * 8);
+    hipMemsetAsync(d_st, 0, (size_t)kMaxBlocksHess * 16 * 8, c->stream);
+    stamps = d_st;
+  }
+  hipLaunchKernelGGL(k_hessian2<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate, stamps);
+  if (want_stamps) {
+    std::vector<long long> h((size_t)nb * 16);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    long long t0 = h[0];
+    for (int b = 0; b < nb; b++) if (h[(size_t)b * 16] && h[(size_t)b * 16] < t0) t0 = h[(size_t)b * 16];
+    for (int b : {0, 1, nb / 2, nb - 1}) {
+      fprintf(stderr, "[k3 stamps] wg %d:", b);
+      for (int i = 0; i < 15; i++) fprintf(stderr, " %lld", h[(size_t)b * 16 + i] ? h[(size_t)b * 16 + i] - t0 : -1);
+      fprintf(stderr, "\n");
+    }
+    long long tmax = 0;
+    for (int b = 0; b < nb; b++) if (h[(size_t)b * 16 + 14] - t0 > tmax) tmax = h[(size_t)b * 16 + 14] - t0;
+    fprintf(stderr, "[k3 stamps] last workgroup ends at %lld ticks (100 MHz wall clock: 1 tick = 10 ns)\n", tmax);
+  }
   *nblocks_out = nb;
   return VBA_OK;
 }
 
 int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb) {
   switch (c->opt.win_size) {
-    case 2: return launch_hessian_t<2>(c, pd, gate, head, end, nb);
-    case 3: return launch_hessian_t<3>(c, pd, gate, head, end, nb);
-    case 4: return launch_hessian_t<4>(c, pd, gate, head, end, nb);
-    case 5: return launch_hessian_t<5>(c, pd, gate, head, end, nb);
-    case 6: return launch_hessian_t<6>(c, pd, gate, head, end, nb);
-    case 8: return launch_hessian_t<8>(c, pd, gate, head, end, nb);
-    case 10: return launch_hessian_t<10>(c, pd, gate, head, end, nb);
-    case 12: return launch_hessian_t<12>(c, pd, gate, head, end, nb);
-    case 16: return launch_hessian_t<16>(c, pd, gate, head, end, nb);
+    case 2: return launch_hessian2_t<2>(c, pd, gate, head, end, nb);
+    case 3: return launch_hessian2_t<3>(c, pd, gate, head, end, nb);
+    case 4: return launch_hessian2_t<4>(c, pd, gate, head, end, nb);
+    case 5: return launch_hessian2_t<5>(c, pd, gate, head, end, nb);
+    case 6: return launch_hessian2_t<6>(c, pd, gate, head, end, nb);
+    case 8: return launch_hessian2_t<8>(c, pd, gate, head, end, nb);
+    case 10: return launch_hessian2_t<10>(c, pd, gate, head, end, nb);
+    case 12: return launch_hessian2_t<12>(c, pd, gate, head, end, nb);
+    case 16: return launch_hessian2_t<16>(c, pd, gate, head, end, nb);
     default: return VBA_ERR_UNSUPPORTED_WINDOW;
   }
 }
 
+void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, int nb) {
+#define VBA_RES_CASE(WW) case WW: hipLaunchKernelGGL(k_residual_w<WW>, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); break;
+  switch (c->opt.win_size) {
+    VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(8) VBA_RES_CASE(10) VBA_RES_CASE(12)
+    default: hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate);
+  }
+#undef VBA_RES_CASE
+}
+
 // device passes on device-resident poses (gate == nullptr: unconditional)
 int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end) {
-  const int W = c->opt.win_size, nout = nout_of(W);
+  const int W = c->opt.win_size, nout = nout_tl(W);
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)nout * sizeof(double), c->stream));
   } else {
@@ -209,7 +251,7 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
     if ((size_t)nb > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
     TimedSpan s1{}, s2{};
     span_begin(c, "residual", s1);
-    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, poses_dev, head, end, c->d_partial, gate);
+    launch_residual(c, poses_dev, gate, head, end, nb);
     span_end(c, "residual", s1);
     span_begin(c, "reduce", s2);
     hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, c->stream, c->d_partial, nb, d_scalar_out, gate);
@@ -223,11 +265,25 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
   return VBA_OK;
 }
 
-// device: d_out[0..nout) = [H | g | r] over voxels [head,end) for host poses (+ all-reduce across ranks when configured)
+// tile layout -> full layout [H | g | r] in d_full (host consumers only; the device LM reads the tile layout directly)
+int tiles_to_full(vba_ctx *c, const double *src) {
+#define VBA_TF_CASE(WW) case WW: hipLaunchKernelGGL(k_tiles_to_full<WW>, dim3(16), dim3(256), 0, c->stream, src, c->d_full); break;
+  switch (c->opt.win_size) {
+    VBA_TF_CASE(2) VBA_TF_CASE(3) VBA_TF_CASE(4) VBA_TF_CASE(5) VBA_TF_CASE(6) VBA_TF_CASE(8) VBA_TF_CASE(10) VBA_TF_CASE(12) VBA_TF_CASE(16)
+    default: return VBA_ERR_UNSUPPORTED_WINDOW;
+  }
+#undef VBA_TF_CASE
+  HIPCHK(c, hipGetLastError());
+  return VBA_OK;
+}
+
+// device: d_full = [H | g | r] over voxels [head,end) for host poses (+ all-reduce across ranks when configured)
 int eval_hessian_dev(vba_ctx *c, const double *poses, int head, int end) {
   int st = upload_poses(c, poses);
   if (st) return st;
-  return hessian_pass(c, c->d_poses, nullptr, head, end);
+  st = hessian_pass(c, c->d_poses, nullptr, head, end);
+  if (st) return st;
+  return tiles_to_full(c, c->d_out);
 }
 
 int eval_residual_dev(vba_ctx *c, const double *poses, int head, int end, double *d_scalar_out) {
@@ -308,14 +364,17 @@ int vba_create(const vba_options *opt, vba_ctx **out) {
   const int W = opt->win_size, nout = nout_of(W);
   c->fv.W = W;
   if (hipMalloc((void **)&c->d_poses, (size_t)VBA_MAX_WIN * 12 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&c->d_out, ((size_t)nout + 64) * sizeof(double)) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
-  if (ensure_partial(c, (size_t)kMaxBlocksHess * nout) != VBA_OK || ensure_pin(c, 65536 + (size_t)nout + 1024) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
-  if (hipMalloc((void **)&c->d_lm, sizeof(LmDev)) != hipSuccess || hipMalloc((void **)&c->d_raw, ((size_t)nout + 64) * 8) != hipSuccess ||
+      hipMalloc((void **)&c->d_out, ((size_t)nout_tl(W) + 64) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&c->d_full, ((size_t)nout + 64) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&c->d_scal, 64 * sizeof(double)) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
+  if (ensure_partial(c, (size_t)kMaxBlocksHess * (nout_tl(W) > nout ? nout_tl(W) : nout)) != VBA_OK || ensure_pin(c, 65536 + (size_t)nout + 1024) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
+  if (hipMalloc((void **)&c->d_lm, sizeof(LmDev)) != hipSuccess || hipMalloc((void **)&c->d_raw, ((size_t)nout_tl(W) + 64) * 8) != hipSuccess ||
       hipHostMalloc((void **)&c->h_lm, sizeof(LmDev), hipHostMallocDefault) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
   {
     const int n = 6 * W, ld = n + 2;
     const int lds = (int)(((size_t)2 * n * ld + 5 * n) * 8 + (size_t)n * 4 + 64);
-    hipFuncSetAttribute((const void *)k_lm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void *)k_lm_solve_g<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void *)k_lm_solve_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   if (opt->max_voxels && factor_reserve(c, (int)opt->max_voxels) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
   map_init(c->map, c->opt);
@@ -328,13 +387,14 @@ void vba_destroy(vba_ctx *c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   map_free(c->map);
-  double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out};
+  double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out, c->d_full, c->d_scal};
   for (double *q : p) if (q) hipFree(q);
   if (c->d_stage) hipFree(c->d_stage);
   if (c->h_pin) hipHostFree(c->h_pin);
   if (c->d_lm) hipFree(c->d_lm);
   if (c->d_raw) hipFree(c->d_raw);
   if (c->h_lm) hipHostFree(c->h_lm);
+  for (int i = 0; i < vba_ctx::kLmRing; i++) { if (c->h_lm_up[i]) hipHostFree(c->h_lm_up[i]); if (c->lm_up_ev[i]) hipEventDestroy(c->lm_up_ev[i]); }
   for (auto &kv : c->spans) for (auto &s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -382,7 +442,7 @@ int vba_factor_acc_evaluate2(vba_ctx *c, const double *poses, int head, int end,
   int st = eval_hessian_dev(c, poses, head, end);
   if (st) return st;
   std::vector<double> buf(nout);
-  st = fetch(c, c->d_out, nout, buf.data());
+  st = fetch(c, c->d_full, nout, buf.data());
   if (st) return st;
   if (Hess) std::memcpy(Hess, buf.data(), (size_t)n * n * sizeof(double));
   if (JacT) std::memcpy(JacT, buf.data() + (size_t)n * n, (size_t)n * sizeof(double));
@@ -392,8 +452,7 @@ int vba_factor_acc_evaluate2(vba_ctx *c, const double *poses, int head, int end,
 
 int vba_factor_evaluate_only_residual(vba_ctx *c, const double *poses, int head, int end, double *residual) {
   if (head < 0 || end > c->nvox || head > end) return VBA_ERR_BAD_ARG;
-  const int nout = nout_of(c->opt.win_size);
-  double *d_r = c->d_out + nout + 8;
+  double *d_r = c->d_scal;
   int st = eval_residual_dev(c, poses, head, end, d_r);
   if (st) return st;
   double r = 0;
@@ -439,8 +498,15 @@ int vba_factor_occupied_slots(vba_ctx *c, long long *slots) {
 // ---------------------------------------------------------------- Lidar_BA_Optimizer (VM:342-498), device-resident loop
 int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   const int W = c->opt.win_size;
-  HIPCHK(c, hipStreamSynchronize(c->stream));     // the pinned mirror may still be in flight from a previous call
-  LmDev *h = c->h_lm;
+  const int slot = c->lm_up_next;
+  c->lm_up_next = (slot + 1) % vba_ctx::kLmRing;
+  if (!c->h_lm_up[slot]) {
+    HIPCHK(c, hipHostMalloc((void **)&c->h_lm_up[slot], sizeof(LmDev), hipHostMallocDefault));
+    HIPCHK(c, hipEventCreateWithFlags(&c->lm_up_ev[slot], hipEventDisableTiming));
+  } else {
+    HIPCHK(c, hipEventSynchronize(c->lm_up_ev[slot]));      // the copy that last used this slot has long completed
+  }
+  LmDev *h = c->h_lm_up[slot];
   std::memset(h, 0, sizeof(LmDev));
   std::memcpy(h->x, poses, (size_t)W * 12 * sizeof(double));
   std::memcpy(h->xt, poses, (size_t)W * 12 * sizeof(double));   // vector<IMUST> x_stats_temp = x_stats  VM:435
@@ -449,9 +515,19 @@ int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   h->run_hess = 1; h->run_res = 1;
   { const char *e = getenv("VBA_DEBUG_SOLVE"); h->pad = e ? atoi(e) : 0; }   // timing ablation knob (0 in production)
   HIPCHK(c, hipMemcpyAsync(c->d_lm, h, sizeof(LmDev), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->lm_up_ev[slot], c->stream));
   c->lm.active = true; c->lm.thd_num = thd_num;
   c->trace.clear();
   return VBA_OK;
+}
+
+// Re-creates the per-voxel eigen state (eig_values / eig_vectors / pcr_adds) at the poses loaded by vba_lm_begin: one
+// residual pass on the device, nothing is fetched.  In the reference this state comes from recut/tras_opt right before
+// damping_iter (VM:1628); a caller that restarts the optimiser on an unchanged factor store uses this instead.
+int vba_lm_refresh_eigen(vba_ctx *c) {
+  if (!c->lm.active) return VBA_ERR_BAD_ARG;
+  const double *x_dev = reinterpret_cast<const double *>(reinterpret_cast<char *>(c->d_lm) + offsetof(LmDev, x));
+  return residual_pass(c, x_dev, nullptr, 0, c->nvox, c->d_scal);
 }
 
 // One trip through the loop body VM:441-494, enqueued without host synchronisation unless the caller asks for the flags.
@@ -480,11 +556,13 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
     default: {
       const int n = 6 * W, ld = n + 2;
       const size_t lds = ((size_t)2 * n * ld + 5 * n) * 8 + (size_t)n * 4 + 64;
-      hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(128), lds, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw, W);
+      if (W == 12) hipLaunchKernelGGL(k_lm_solve_g<12>, dim3(1), dim3(128), lds, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw);
+      else if (W == 16) hipLaunchKernelGGL(k_lm_solve_g<16>, dim3(1), dim3(128), lds, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw);
+      else return VBA_ERR_UNSUPPORTED_WINDOW;
     }
   }
   span_end(c, "solve", sp);
-  double *d_r = c->d_out + nout + 8;
+  double *d_r = c->d_scal;
   if (c->allreduce && c->n_ranks > 1) {
     st = residual_pass(c, xt_dev, run_res, 0, V, d_r);                // only_residual  VM:467 (+ scalar all-reduce)
     if (st) return st;
@@ -493,7 +571,7 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
     const int nb = (V + 63) / 64;
     TimedSpan s1{};
     span_begin(c, "residual", s1);
-    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, xt_dev, 0, V, c->d_partial, run_res);
+    launch_residual(c, xt_dev, run_res, 0, V, nb);
     span_end(c, "residual", s1);
     hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_partial, nb, W);   // sums the partials itself
   }
@@ -510,12 +588,15 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
 int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (!c->lm.active) return VBA_ERR_BAD_ARG;
   const int W = c->opt.win_size, n = 6 * W;
+  if (!poses && !hess && !resis2) { c->lm.active = false; return VBA_OK; }    // nothing requested: no synchronisation
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
   if (hess) {
     int st = ensure_pin(c, 65536 + (size_t)n * n + 1024);
     if (st) return st;
     const double *src = (c->allreduce && c->n_ranks > 1) ? c->d_raw : c->d_out;    // *hess = Hess before gauge fixing (VM:446)
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, src, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    st = tiles_to_full(c, src);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, c->d_full, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const LmDev *h = c->h_lm;
@@ -523,6 +604,12 @@ int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (hess) std::memcpy(hess, c->h_pin + 32768, (size_t)n * n * sizeof(double));
   if (resis2) { resis2[0] = h->resis_first; resis2[1] = h->r2; }
   c->trace.assign(h->trace, h->trace + 5 * h->n_trace);
+  if (h->pad & 16) {
+    fprintf(stderr, "[solve stamps, shader cycles rel. to factorisation start]");
+    for (int i = 1; i <= 30; i++) fprintf(stderr, " %lld", h->stamps[i] - h->stamps[50]);
+    fprintf(stderr, " | subst end %lld | shader clock %.0f MHz\n", h->stamps[40] - h->stamps[0],
+            100.0 * (double)(h->stamps[51] - h->stamps[50]) / (double)(h->stamps[40] - h->stamps[0]));
+  }
   c->lm.active = false;
   return VBA_OK;
 }
@@ -596,7 +683,7 @@ int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity
       for (double &h : Hess) h *= imu_coef;                           // VM:565-567
       for (double &j : JacT) j *= imu_coef;
       residual *= (imu_coef * 0.5);
-      st = fetch(c, c->d_out, nout, lid.data());
+      st = fetch(c, c->d_full, nout, lid.data());
       if (st) return st;
       for (int i = 0; i < W; i++) {                                   // hess_plus VM:509-517
         for (int r = 0; r < 6; r++) JacT[i * DIM + r] += lid[(size_t)n6 * n6 + i * 6 + r];
@@ -636,7 +723,7 @@ int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity
     for (int r = 0; r < imu_leng; r++) q1 += dxi[r] * (u * Hess[(size_t)r * imu_leng + r] * dxi[r] - JacT[r]);
     q1 *= 0.5;
     states_to_poses(reinterpret_cast<double *>(xt.data()), W, poses.data());
-    double *d_r = c->d_out + nout + 8;
+    double *d_r = c->d_scal;
     int st = eval_residual_dev(c, poses.data(), 0, V, d_r);           // only_residual VM:586-622 / VM:831-870
     if (st) return st;
     const double r_imu = imu_resid(xt);
