@@ -1,0 +1,73 @@
+"""GPU test of the sharded path (2 ranks sharing the one card, gloo as the transport): every rank inserts only the points of
+its own voxel-bucket range (K1 filter), builds its own octree / factor store, and the device-resident LM loop all-reduces
+the packed Hessian buffer and the residual scalar through the vba_set_allreduce hook.  The refined poses must equal the
+single-rank result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import synth, capi
+    wl = synth.CONFIGS["room20k_w4"]
+    s = synth.make_scans(wl)
+    W = wl.win_size
+    poses = synth.poses_flat(s["R0"], s["p0"])
+
+    def run(shard):
+        ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+        if shard:
+            ctx.set_shard(rank, world)
+            cache = {}
+
+            def hook(ptr, n, _stream):
+                if (ptr, n) not in cache:
+                    class _Ext:
+                        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
+                    cache[(ptr, n)] = torch.as_tensor(_Ext(), device="cuda")
+                dist.all_reduce(cache[(ptr, n)], op=dist.ReduceOp.SUM)
+                return 0
+            ctx.set_allreduce(hook)
+        for i in range(W):
+            ctx.cut_voxel(i, s["points"][i], poses[i])
+        ctx.recut(W, poses, multi=False)
+        nv = ctx.size()
+        out = ctx.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
+        return nv, out
+
+    nv_s, sharded = run(True)
+    cnt = torch.tensor([nv_s]); dist.all_reduce(cnt)
+    if rank == 0:
+        nv_f, full = run(False)
+        ok = (int(cnt.item()) == nv_f and np.abs(sharded["poses"] - full["poses"]).max() < 1e-8
+              and np.allclose(sharded["trace"], full["trace"], rtol=1e-7, atol=1e-12)
+              and np.abs(sharded["hess"] - full["hess"]).max() < 1e-8 * np.abs(full["hess"]).max())
+        open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write(
+            "%d %d %g" % (int(cnt.item()), nv_f, np.abs(sharded["poses"] - full["poses"]).max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_lm_equals_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    files = [p.name for p in tmp_path.iterdir()]
+    assert "ok" in files, [(p.name, p.read_text()) for p in tmp_path.iterdir()]
