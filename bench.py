@@ -79,6 +79,33 @@ def cpu_baseline(wl, scans, poses0, budget_s=15.0):
                        % (reps, iters, len(fac["coe"]), os.cpu_count(), sum(len(p) for p in scans["points"]), t_build))
 
 
+def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16):
+    """The residual pass K4 on `copies` disjoint translated copies of the scene inserted through K1/K2 (V x copies)."""
+    import ctypes as C
+    W = wl.win_size
+    ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+    R = poses0[:, :9].reshape(W, 3, 3)
+    for i in range(W):
+        pts = scans["points"][i]
+        tiles = [pts + (R[i].T @ np.array([100.0 * (c % 4), 100.0 * (c // 4), 0.0]))[None, :] for c in range(copies)]
+        ctx.cut_voxel(i, np.concatenate(tiles), poses0[i])
+    ctx.recut(W, poses0, multi=False)
+    V = ctx.size()
+    occ = ctx.factor_occupancy()
+    for _ in range(3):
+        ctx.evaluate_only_residual(poses0)
+    ctx.timing_enable(True); ctx.timing_select("residual"); ctx.timing_reset()
+    for _ in range(20):
+        ctx.evaluate_only_residual(poses0)
+    t, n = ctx.timing_get("residual")
+    us = t / max(n, 1)
+    by = V * ((occ + 1) * 80 + W * 8 + 8 + 176)
+    gbs = by / (us * 1e-6) / 1e9
+    ctx.close()
+    return {"voxels": V, "occupied_frames_per_voxel": occ, "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch": by,
+            "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="hesai200k_w10")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaled", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -207,13 +235,29 @@ def main():
     dominant = "hessian" if t_hes >= t_res else "residual"
     res_gbs = bytes_res / (res_us * 1e-6) / 1e9 if res_us > 0 else 0.0
     hes_gbs = bytes_hes / (hes_us * 1e-6) / 1e9 if hes_us > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": "k_residual (K4, evaluate_only_residual)", "achieved": res_gbs, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": res_gbs / HBM_PEAK_GBS, "traffic": None,
+    # HBM traffic of K4 from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # runs of this same command; gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE x2; 8-B-per-lane accesses are
+    # "uncalibrated" there, so this is an upper estimate)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")))
+        k4 = [v for k, v in pmc.items() if k.startswith("void vba::k_residual_w<10")][0]
+        if args.workload == "hesai200k_w10" and world == 1:
+            traffic = (2.0 * k4["FETCH_SIZE_KB_p75"] + k4["WRITE_SIZE_KB_p75"]) * 1024.0
+    except Exception:
+        pass
+    roof = {"bound": "hbm", "kernel": "k_residual_w<10> (K4, evaluate_only_residual)", "achieved": res_gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": res_gbs / HBM_PEAK_GBS, "traffic": traffic,
             "avg_launch_us": res_us, "launches": n_res, "algorithmic_bytes_per_launch": bytes_res,
-            "other_kernels": {"k_hessian (K3, acc_evaluate2)": {"avg_launch_us": hes_us, "launches": n_hes, "algorithmic_GBps": hes_gbs,
+            "other_kernels": {"k_hessian2<10> (K3, acc_evaluate2; average incl. the launches gated off after a rejected step)": {"avg_launch_us": hes_us, "launches": n_hes, "algorithmic_GBps": hes_gbs,
                                                                 "algorithmic_bytes_per_launch": bytes_hes},
                               "k_lm_solve (gauge + LDLT + retraction)": {"avg_launch_us": t_sol / max(n_sol, 1), "launches": n_sol}},
             "dominant_by_time": dominant}
+
+    # K4 on the same scene tiled 16x (the pass then exceeds the 256 MB Infinity Cache and fills the chip)
+    scaled = None
+    if world == 1 and not args.no_scaled:
+        scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16)
 
     if rank == 0:
         out = {
@@ -225,6 +269,7 @@ def main():
                                    % (wl.name, wl.n_pts, W, wl.voxel_size, V_total, occ),
                        "parallelism": "voxel-bucket shard x%d + all-reduce of [H|g|r]" % world if world > 1 else "single GPU"},
             "roofline": roof,
+            "roofline_residual_pass_scene_x16": scaled,
             "full_window_rebuild": {"points": n_points, "wall_ms": 1e3 * t_rebuild, "insert_device_ms": 1e-3 * t_ins / max(n_rebuild, 1),
                                     "recut_extract_device_ms": 1e-3 * t_rec / max(n_rebuild, 1),
                                     "insert_algorithmic_GBps": n_points * 24 / (t_ins / max(n_rebuild, 1) * 1e-6) / 1e9 if t_ins > 0 else None},

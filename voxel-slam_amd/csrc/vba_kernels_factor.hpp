@@ -195,7 +195,9 @@ __global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__r
 //            are masked off, so empty slots still cost 8 B, not 80 B);
 //   then transforms, Jacobi eigen-solve, write-back.  The generic kernel above pays one dependent round trip per frame.
 // Poses are read through uniform (scalar) loads: the frame index is a compile-time constant after unrolling.
-template <int W>
+// NB = number of load batches: 1 keeps all 9W cluster scalars in flight (best when the pass is latency-bound, < 1 wave per
+// SIMD); 2 halves the register footprint (<= 128 VGPRs -> 4 waves per SIMD) for passes that fill the chip.
+template <int W, int NB>
 __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *__restrict__ poses, int head, int end,
                                                    double *__restrict__ partial, const int *__restrict__ gate) {
   if (gate && *gate == 0) return;
@@ -211,19 +213,24 @@ __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *_
     double s0 = f.fix[6 * vs + v], s1 = f.fix[7 * vs + v], s2 = f.fix[8 * vs + v];
     double N = f.fix[9 * vs + v];
     const double coe = f.coe[v];
-    double c[W][9];
+    constexpr int WB = (W + NB - 1) / NB;
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-      const bool occ = nn[i] != 0.0;
+    for (int bt = 0; bt < NB; bt++) {
+    double c[WB][9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) c[i][k] = occ ? f.cl[(size_t)k * fs + (size_t)i * vs + v] : 0.0;
+    for (int ii = 0; ii < WB; ii++) {
+      const int i = bt * WB + ii;
+      const bool occ = i < W && nn[i < W ? i : 0] != 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) c[ii][k] = occ ? f.cl[(size_t)k * fs + (size_t)i * vs + v] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-      const double n = nn[i];
+    for (int ii = 0; ii < WB; ii++) {
+      const int i = bt * WB + ii;
+      const double n = i < W ? nn[i < W ? i : 0] : 0.0;
       if (n != 0.0) {
-        const double pxx = c[i][0], pxy = c[i][1], pxz = c[i][2], pyy = c[i][3], pyz = c[i][4], pzz = c[i][5];
-        const double vx = c[i][6], vy = c[i][7], vz = c[i][8];
+        const double pxx = c[ii][0], pxy = c[ii][1], pxz = c[ii][2], pyy = c[ii][3], pyz = c[ii][4], pzz = c[ii][5];
+        const double vx = c[ii][6], vy = c[ii][7], vz = c[ii][8];
         const double *R = poses + 12 * i;
         const double tx = R[9], ty = R[10], tz = R[11];
         const double rv0 = R[0] * vx + R[1] * vy + R[2] * vz;
@@ -241,6 +248,7 @@ __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *_
         s0 += rv0 + n * tx; s1 += rv1 + n * ty; s2 += rv2 + n * tz;
         N += n;
       }
+    }
     }
     const double b0 = s0 / N, b1 = s1 / N, b2 = s2 / N;
     double w0, w1, w2, V[9];

@@ -211,7 +211,10 @@ int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int 
 }
 
 void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, int nb) {
-#define VBA_RES_CASE(WW) case WW: hipLaunchKernelGGL(k_residual_w<WW>, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); break;
+  // below ~1 wave per SIMD the pass is latency-bound: one load batch; above it, two batches for 4-wave occupancy
+  const bool big = nb > 2048;
+#define VBA_RES_CASE(WW) case WW: if (big) hipLaunchKernelGGL((k_residual_w<WW, 3>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); \
+    else hipLaunchKernelGGL((k_residual_w<WW, 1>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); break;
   switch (c->opt.win_size) {
     VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(8) VBA_RES_CASE(10) VBA_RES_CASE(12)
     default: hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate);
