@@ -187,6 +187,8 @@ int vba_timing_enable(vba_ctx *ctx, int on);
 /* Restrict the event bracketing to one kernel family (NULL / "" = all): two hipEventRecord calls per launch cost host
  * time, so the headline timed region brackets only the kernel whose roofline is reported. */
 int vba_timing_select(vba_ctx *ctx, const char *name);
+/* Records an event pair around no work under the name "null": the overhead that every bracketed launch carries. */
+int vba_timing_null_span(vba_ctx *ctx);
 int vba_timing_reset(vba_ctx *ctx);
 /* name in {"residual","hessian","reduce","solve","insert","recut","margi"}; returns launches in *count. */
 int vba_timing_get(vba_ctx *ctx, const char *name, double *total_us, int *count);

@@ -29,7 +29,7 @@ EXPORTS = [
     "vba_map_cut_voxel", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
-    "vba_timing_enable", "vba_timing_select", "vba_timing_reset", "vba_timing_get",
+    "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
     "vba_lm_begin", "vba_lm_refresh_eigen", "vba_lm_iterate", "vba_lm_end",
 ]
 
@@ -308,6 +308,13 @@ class Context:
 
     def timing_select(self, name=None):
         self.lib.vba_timing_select(self.h, name.encode() if name else None)
+
+    def timing_null_spans(self, n=64):
+        """Average duration in microseconds of an event pair that brackets nothing."""
+        for _ in range(n):
+            self.lib.vba_timing_null_span(self.h)
+        t, k = self.timing_get("null")
+        return t / max(k, 1)
 
     def timing_reset(self):
         self.lib.vba_timing_reset(self.h)

@@ -794,6 +794,16 @@ int vba_set_shard(vba_ctx *c, int rank, int n_ranks) {
 
 // ---------------------------------------------------------------- timing
 int vba_timing_enable(vba_ctx *c, int on) { c->timing = on != 0; return VBA_OK; }
+int vba_timing_null_span(vba_ctx *c) {   // an event pair around nothing: the bracketing overhead itself (recorded as "null")
+  TimedSpan s{};
+  const bool was = c->timing;
+  const std::string only = c->timing_only;
+  c->timing = true; c->timing_only.clear();
+  span_begin(c, "null", s);
+  span_end(c, "null", s);
+  c->timing = was; c->timing_only = only;
+  return VBA_OK;
+}
 int vba_timing_select(vba_ctx *c, const char *name) { c->timing_only = name ? name : ""; return VBA_OK; }
 int vba_timing_reset(vba_ctx *c) {
   hipStreamSynchronize(c->stream);
