@@ -128,39 +128,55 @@ __device__ __forceinline__ void init_node(const MapView &m, int id, unsigned lon
 
 // ------------------------------------------------------------------------------------------------ K1: insert
 // Phase 1: world transform, key, find-or-claim the hash slot of the root voxel.
-__global__ void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given) {
+__global__ void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given, int stamp) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
-  double x, y, z;
-  if (world_given) {  // fixed points arrive in world coordinates, staged in the pool tail (see map_cut_voxel_fix)
-    x = m.fx[(size_t)0 * m.cap_fix + slot + p]; y = m.fx[(size_t)1 * m.cap_fix + slot + p]; z = m.fx[(size_t)2 * m.cap_fix + slot + p];
-  } else {
-    const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-    const double *R = m.poses;  // the scan pose is staged at poses[0..12)
-    x = R[0] * bx + R[1] * by + R[2] * bz + R[9]; y = R[3] * bx + R[4] * by + R[5] * bz + R[10]; z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
-  }
-  const long long kx = key_axis(x, P.voxel_size), ky = key_axis(y, P.voxel_size), kz = key_axis(z, P.voxel_size);
-  m.phash[p] = -1;
-  if (kx < -KEY_OFF || kx >= KEY_OFF || ky < -KEY_OFF || ky >= KEY_OFF || kz < -KEY_OFF || kz >= KEY_OFF) { atomicAdd(&m.cnt[CNT_BADKEY], 1); return; }
-  if (P.n_ranks > 1 && (int)((shard_bucket(kx, ky, kz) * (uint64_t)P.n_ranks) >> 16) != P.rank) return;  // not this rank's bucket range
-  const unsigned long long key = pack_key(kx, ky, kz);
-  unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & m.hmask;
-  for (unsigned int probe = 0; probe <= m.hmask; probe++) {
-    unsigned long long cur = m.hkeys[h];
-    if (cur == key) break;
-    if (cur == KEY_EMPTY) {
-      const unsigned long long prev = atomicCAS(&m.hkeys[h], KEY_EMPTY, key);
-      if (prev == KEY_EMPTY) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = (int)h; break; }
-      if (prev == key) break;
+  int hslot = -1, root = -1;
+  if (p < n) {
+    double x, y, z;
+    if (world_given) {  // fixed points arrive in world coordinates, staged in the pool tail (see map_cut_voxel_fix)
+      x = m.fx[(size_t)0 * m.cap_fix + slot + p]; y = m.fx[(size_t)1 * m.cap_fix + slot + p]; z = m.fx[(size_t)2 * m.cap_fix + slot + p];
+    } else {
+      const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+      const double *R = m.poses;  // the scan pose is staged at poses[0..12)
+      x = R[0] * bx + R[1] * by + R[2] * bz + R[9]; y = R[3] * bx + R[4] * by + R[5] * bz + R[10]; z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
     }
-    h = (h + 1) & m.hmask;
+    const long long kx = key_axis(x, P.voxel_size), ky = key_axis(y, P.voxel_size), kz = key_axis(z, P.voxel_size);
+    bool ok = true;
+    if (kx < -KEY_OFF || kx >= KEY_OFF || ky < -KEY_OFF || ky >= KEY_OFF || kz < -KEY_OFF || kz >= KEY_OFF) { atomicAdd(&m.cnt[CNT_BADKEY], 1); ok = false; }
+    if (ok && P.n_ranks > 1 && (int)((shard_bucket(kx, ky, kz) * (uint64_t)P.n_ranks) >> 16) != P.rank) ok = false;  // not this rank's bucket range
+    if (ok) {
+      const unsigned long long key = pack_key(kx, ky, kz);
+      unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & m.hmask;
+      for (unsigned int probe = 0; probe <= m.hmask; probe++) {
+        unsigned long long cur = m.hkeys[h];
+        if (cur == key) break;
+        if (cur == KEY_EMPTY) {
+          const unsigned long long prev = atomicCAS(&m.hkeys[h], KEY_EMPTY, key);
+          if (prev == KEY_EMPTY) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = (int)h; break; }
+          if (prev == key) break;
+        }
+        h = (h + 1) & m.hmask;
+      }
+      hslot = (int)h;
+      // hvals is only written by the next kernel, so a valid id here means "this root existed before the call"
+      if (!world_given) root = m.hvals[h];
+    }
+    m.phash[p] = hslot;
   }
-  m.phash[p] = (int)h;
+  // Roots that existed before this call are marked here (isexist, sliding-map membership, per-scan touch count:
+  // VM:1997-2001); roots created by this call are marked by k_ins_newroots.  Consecutive points of a scan mostly share
+  // their root: only the first lane of each run issues the (contended) atomics.
+  const int prev_root = __shfl_up(root, 1, 64);
+  if (root >= 0 && ((threadIdx.x & 63) == 0 || prev_root != root)) {
+    m.f_exist[root] = 1;
+    if (m.f_slide[root] == 0 && atomicExch(&m.f_slide[root], 1) == 0) atomicAdd(&m.cnt[CNT_SLIDE], 1);
+    if (m.nstamp[root] != stamp && atomicExch(&m.nstamp[root], stamp) != stamp) atomicAdd(&m.cnt[CNT_TOUCH], 1);
+  }
 }
 
 // Phase 2: one thread per newly claimed hash slot creates the root node (VM:1935-1946).
-__global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour) {
+__global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, int stamp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.cnt[CNT_NEWSLOTS]) return;
   const int h = m.newslots[i];
@@ -171,49 +187,71 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour) 
   unpack_key(key, kx, ky, kz);
   init_node(m, id, key, id, -1, 0, 0, (0.5 + kx) * P.voxel_size, (0.5 + ky) * P.voxel_size, (0.5 + kz) * P.voxel_size, (float)(P.voxel_size / 4.0));
   if (is_fix) m.njour[id] = jour;   // VM:2147
+  else {                            // VM:2016-2017: a root created by a window scan enters the sliding map
+    m.f_exist[id] = 1; m.f_slide[id] = 1; m.nstamp[id] = stamp;
+    atomicAdd(&m.cnt[CNT_SLIDE], 1); atomicAdd(&m.cnt[CNT_TOUCH], 1);
+  }
   m.hvals[h] = id;
   atomicAdd(&m.cnt[CNT_ROOTS], 1);
 }
 
-// Phase 3 (window scans only): mark roots (isexist, sliding map membership, per-scan touch count) VM:1997-2001, 2016-2017.
-__global__ void k_ins_touch(MapView m, int n, int stamp) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int h = m.phash[p];
-  if (h < 0) return;
-  const int root = m.hvals[h];
-  if (root < 0) return;
-  m.f_exist[root] = 1;
-  if (m.f_slide[root] == 0 && atomicExch(&m.f_slide[root], 1) == 0) atomicAdd(&m.cnt[CNT_SLIDE], 1);
-  if (m.nstamp[root] != stamp && atomicExch(&m.nstamp[root], stamp) != stamp) atomicAdd(&m.cnt[CNT_TOUCH], 1);
-}
-
-// Phase 4: descend to the leaf and accumulate (OctoTree::allocate VM:1204 -> push VM:1105-1143).
-__global__ void k_ins_accum(MapView m, MapParams P, int slot, int n, int multi, int has_var) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+// Phase 3: descend to the leaf and accumulate (OctoTree::allocate VM:1204 -> push VM:1105-1143).
+// Neighbouring points of a scan fall into the same few leaves, so the 20 cluster scalars (body-frame slot cluster +
+// world-frame pcr_add) are first summed per leaf in an LDS hash table of the workgroup (ds_add_f64) and only the table's
+// occupied entries go to HBM as f64 atomics: ~N_leaves x 20 instead of 256 x 20 global atomics per workgroup.
+__global__ __launch_bounds__(256) void k_ins_accum(MapView m, MapParams P, int slot, int n, int multi, int has_var) {
+  __shared__ int tkey[512];
+  __shared__ double tacc[20][512];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < 512; t += 256) tkey[t] = -1;
+  for (int t = tid; t < 20 * 512; t += 256) (&tacc[0][0])[t] = 0.0;
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + tid;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
-  int *pn = m.pnode + (size_t)slot * mpz + p;
-  *pn = -1;
-  if (multi && m.cnt[CNT_TOUCH] < P.thread_num) return;   // VM:2044-2045: the scan is dropped
-  const int h = m.phash[p];
-  if (h < 0) return;
-  int node = m.hvals[h];
-  if (node < 0) return;
-  const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-  const double *R = m.poses;
-  const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
-  while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
-  atomic_cluster_add(m.nlc + (size_t)slot * cp + node, W * cp, bx, by, bz);   // sw->pcrs_local[mord].push(pv.pnt)  VM:1134
-  atomic_cluster_add(m.nadd + node, cp, x, y, z);                             // pcr_add.push(pw)              VM:1136
-  if (has_var) {
-    double var[9];
+  const bool dropped = multi && m.cnt[CNT_TOUCH] < P.thread_num;   // VM:2044-2045: the scan is dropped
+  if (p < n) {
+    int *pn = m.pnode + (size_t)slot * mpz + p;
+    *pn = -1;
+    const int h = m.phash[p];
+    int node = (!dropped && h >= 0) ? m.hvals[h] : -1;
+    if (node >= 0) {
+      const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+      const double *R = m.poses;
+      const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
+      while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+      unsigned int e = ((unsigned int)node * 2654435761u) >> 23;
+      while (true) {
+        const int old = atomicCAS(&tkey[e], -1, node);
+        if (old == -1 || old == node) break;
+        e = (e + 1) & 511;
+      }
+      // sw->pcrs_local[mord].push(pv.pnt) VM:1134 ; pcr_add.push(pw) VM:1136
+      unsafeAtomicAdd(&tacc[0][e], bx * bx); unsafeAtomicAdd(&tacc[1][e], bx * by); unsafeAtomicAdd(&tacc[2][e], bx * bz);
+      unsafeAtomicAdd(&tacc[3][e], by * by); unsafeAtomicAdd(&tacc[4][e], by * bz); unsafeAtomicAdd(&tacc[5][e], bz * bz);
+      unsafeAtomicAdd(&tacc[6][e], bx); unsafeAtomicAdd(&tacc[7][e], by); unsafeAtomicAdd(&tacc[8][e], bz); unsafeAtomicAdd(&tacc[9][e], 1.0);
+      unsafeAtomicAdd(&tacc[10][e], x * x); unsafeAtomicAdd(&tacc[11][e], x * y); unsafeAtomicAdd(&tacc[12][e], x * z);
+      unsafeAtomicAdd(&tacc[13][e], y * y); unsafeAtomicAdd(&tacc[14][e], y * z); unsafeAtomicAdd(&tacc[15][e], z * z);
+      unsafeAtomicAdd(&tacc[16][e], x); unsafeAtomicAdd(&tacc[17][e], y); unsafeAtomicAdd(&tacc[18][e], z); unsafeAtomicAdd(&tacc[19][e], 1.0);
+      if (has_var) {
+        double var[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
-    atomic_bfvar_add(m.ncov + node, cp, var, x, y, z);                        // cov_add += Bf_var(pv, pw)      VM:1138-1140
+        for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+        atomic_bfvar_add(m.ncov + node, cp, var, x, y, z);                      // cov_add += Bf_var(pv, pw)      VM:1138-1140
+      }
+      m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1;
+      *pn = node;
+    }
   }
-  m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1;
-  *pn = node;
+  __syncthreads();
+  for (int t = tid; t < 20 * 512; t += 256) {
+    const int k = t >> 9, e = t & 511;
+    const int node = tkey[e];
+    if (node < 0) continue;
+    const double v = tacc[k][e];
+    if (v == 0.0) continue;
+    if (k < 10) unsafeAtomicAdd(m.nlc + ((size_t)k * W + slot) * cp + node, v);
+    else unsafeAtomicAdd(m.nadd + (size_t)(k - 10) * cp + node, v);
+  }
 }
 
 // Fixed points (VM:2108-2152): new root -> push_fix_novar on the root; else allocate_fix (descend while layer < max_layer).
@@ -620,6 +658,11 @@ struct MapStore {
   int epoch = 1, stamp = 1;
   unsigned int hcap = 0;
   int *h_cnt = nullptr;    // pinned
+  // Inserts are enqueued without reading the counters back: the host keeps pessimistic upper bounds (every point may
+  // create a root) and re-reads the true counters only when a bound would exceed a capacity.
+  long long ub_nodes = 0, ub_roots = 0;
+  bool cnt_stale = false;
+  double *h_pose_ring = nullptr; hipEvent_t pose_ev[8] = {nullptr}; int pose_next = 0;
   void *d_stage = nullptr; size_t stage_bytes = 0;
 };
 
@@ -677,6 +720,7 @@ inline int grow_arrays(std::vector<DevArr> arrs, size_t oldcap, size_t newcap, s
 inline int map_read_counters(MapStore &s, hipStream_t st, std::string &err) {
   MAPCHK(hipMemcpyAsync(s.h_cnt, s.v.cnt, CNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
   MAPCHK(hipStreamSynchronize(st));
+  s.ub_nodes = s.h_cnt[CNT_NODES]; s.ub_roots = s.h_cnt[CNT_ROOTS]; s.cnt_stale = false;
   return VBA_OK;
 }
 
@@ -739,7 +783,7 @@ inline int map_ensure(MapStore &s, hipStream_t st, size_t need_nodes, size_t nee
     s.v.cap_fix = (int)nc;
   }
   // keep the hash table under ~50 % load
-  const size_t want = 2 * ((size_t)s.h_cnt[CNT_ROOTS] + need_pts);
+  const size_t want = 2 * ((size_t)s.ub_roots + need_pts);
   while ((size_t)s.hcap < want && s.hcap < (1u << 30)) {
     int r = map_hash_alloc(s, s.hcap * 2, st, err);
     if (r) return r;
@@ -758,6 +802,8 @@ inline void map_free(MapStore &s) {
   if (s.v.cnt) hipFree(s.v.cnt);
   if (s.v.poses) hipFree(s.v.poses);
   if (s.h_cnt) hipHostFree(s.h_cnt);
+  if (s.h_pose_ring) hipHostFree(s.h_pose_ring);
+  for (int i = 0; i < 8; i++) if (s.pose_ev[i]) hipEventDestroy(s.pose_ev[i]);
   if (s.d_stage) hipFree(s.d_stage);
   s.v = MapView{};
   s.allocated = false;
@@ -776,10 +822,10 @@ inline int map_stage(MapStore &s, size_t bytes, std::string &err) {
   s.stage_bytes = bytes;
   return VBA_OK;
 }
-inline int map_set_counter(MapStore &s, hipStream_t st, int which, int val, std::string &err) {
-  s.h_cnt[CNT_N + 1] = val;
-  MAPCHK(hipMemcpyAsync(s.v.cnt + which, &s.h_cnt[CNT_N + 1], sizeof(int), hipMemcpyHostToDevice, st));
-  MAPCHK(hipStreamSynchronize(st));
+__global__ void k_set_counter(int *cnt, int which, int val) { cnt[which] = val; }
+inline int map_set_counter(MapStore &s, hipStream_t st, int which, int val, std::string &err) {   // stream-ordered, no host sync
+  hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, which, val);
+  MAPCHK(hipGetLastError());
   return VBA_OK;
 }
 
@@ -790,7 +836,11 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   if (win_count < 0 || win_count >= W || n < 0 || !pose || (n > 0 && !pnt_body)) return VBA_ERR_BAD_ARG;
   int r = map_base(s, st, err);
   if (r) return r;
-  r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + (size_t)n + 64, (size_t)n, (size_t)1, err);
+  if (s.cnt_stale && (s.ub_nodes + n + 64 > (long long)s.v.cap || 2 * (s.ub_roots + n) > (long long)s.hcap)) {
+    r = map_read_counters(s, st, err);      // bounds too pessimistic for the current capacity: fetch the true counts
+    if (r) return r;
+  }
+  r = map_ensure(s, st, (size_t)s.ub_nodes + (size_t)n + 64, (size_t)n, (size_t)1, err);
   if (r) return r;
   const int slot = s.mp[win_count];
   s.npts[slot] = n;
@@ -809,7 +859,15 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
     }
   }
   if (var) s.have_var = true;
-  MAPCHK(hipMemcpyAsync(s.v.poses, pose, 12 * sizeof(double), hipMemcpyHostToDevice, st));
+  {  // pose upload through a pinned ring: no implicit synchronisation of a pageable copy
+    if (!s.h_pose_ring) MAPCHK(hipHostMalloc((void **)&s.h_pose_ring, 8 * 12 * sizeof(double), hipHostMallocDefault));
+    const int k = s.pose_next; s.pose_next = (k + 1) & 7;
+    if (!s.pose_ev[k]) MAPCHK(hipEventCreateWithFlags(&s.pose_ev[k], hipEventDisableTiming));
+    else MAPCHK(hipEventSynchronize(s.pose_ev[k]));
+    std::memcpy(s.h_pose_ring + 12 * k, pose, 12 * sizeof(double));
+    MAPCHK(hipMemcpyAsync(s.v.poses, s.h_pose_ring + 12 * k, 12 * sizeof(double), hipMemcpyHostToDevice, st));
+    MAPCHK(hipEventRecord(s.pose_ev[k], st));
+  }
   const MapParams P = map_params(s);
   const int nb = (n + 255) / 256;
   if (n < s.v.max_pts)   // stale assignments of the slot's previous occupant must not survive
@@ -817,15 +875,14 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   hipLaunchKernelGGL(k_scan_to_soa, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var);
   r = map_set_counter(s, st, CNT_NEWSLOTS, 0, err); if (r) return r;
   r = map_set_counter(s, st, CNT_TOUCH, 0, err); if (r) return r;
-  hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, 0);
-  hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0);
   s.stamp++;
-  hipLaunchKernelGGL(k_ins_touch, dim3(nb), dim3(256), 0, st, s.v, n, s.stamp);
+  hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, 0, s.stamp);
+  hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0, s.stamp);
   hipLaunchKernelGGL(k_ins_accum, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0, var ? 1 : 0);
   MAPCHK(hipGetLastError());
-  r = map_read_counters(s, st, err);
-  if (r) return r;
-  if (s.h_cnt[CNT_OVERFLOW]) { err = "voxel map node capacity exceeded during insert"; return VBA_ERR_CAPACITY; }
+  // no read-back: capacity was reserved for the worst case (n new roots), so this call cannot overflow
+  s.ub_nodes += n; s.ub_roots += n; s.cnt_stale = true;
+  if (!is_device_ptr(pnt_body)) MAPCHK(hipStreamSynchronize(st));   // the caller's host buffers may go away
   return VBA_OK;
 }
 
@@ -834,6 +891,7 @@ inline int map_cut_voxel_fix(MapStore &s, hipStream_t st, int n, const double *p
   if (n == 0) return VBA_OK;
   int r = map_base(s, st, err);
   if (r) return r;
+  if (s.cnt_stale) { r = map_read_counters(s, st, err); if (r) return r; }
   r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + (size_t)n + 64, (size_t)n, (size_t)s.h_cnt[CNT_FIX] + (size_t)n, err);
   if (r) return r;
   const double *d_pts = pnt_world;
@@ -849,8 +907,8 @@ inline int map_cut_voxel_fix(MapStore &s, hipStream_t st, int n, const double *p
   hipLaunchKernelGGL(k_fix_to_soa, dim3(nb), dim3(256), 0, st, s.v, base, n, d_pts);
   r = map_set_counter(s, st, CNT_NEWSLOTS, 0, err); if (r) return r;
   r = map_set_counter(s, st, CNT_FIX, base + n, err); if (r) return r;
-  hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, base, n, 1);
-  hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 1, jour);
+  hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, base, n, 1, 0);
+  hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 1, jour, 0);
   hipLaunchKernelGGL(k_fix_accum, dim3(nb), dim3(256), 0, st, s.v, P, base, n);
   MAPCHK(hipGetLastError());
   r = map_read_counters(s, st, err);
@@ -978,7 +1036,7 @@ inline int map_reset(MapStore &s, hipStream_t st, std::string &err) {
   MAPCHK(hipStreamSynchronize(st));
   std::memset(s.h_cnt, 0, CNT_N * sizeof(int));
   for (int i = 0; i < VBA_MAX_WIN; i++) { s.mp[i] = i; s.npts[i] = 0; }
-  s.have_var = false;
+  s.have_var = false; s.ub_nodes = 0; s.ub_roots = 0; s.cnt_stale = false;
   return VBA_OK;
 }
 
