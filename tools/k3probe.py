@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import voxel_slam_amd
 from voxel_slam_amd import capi, synth
@@ -9,5 +9,6 @@ poses = synth.poses_flat(s["R0"], s["p0"])
 ctx = capi.Context(capi.options_from_workload(wl))
 for i in range(wl.win_size): ctx.cut_voxel(i, s["points"][i], poses[i])
 ctx.recut(wl.win_size, poses, multi=False)
+print("V", ctx.size())
 for k in range(3):
-    ctx.lidar_ba_damping_iter(poses, max_iter=1)
+    ctx.acc_evaluate2(poses)

@@ -24,30 +24,41 @@ struct FactorView {
 // Symmetric 3x3 eigen-decomposition, ascending eigenvalues, orthonormal eigenvectors in columns.
 // Cyclic Jacobi in registers (no indexed arrays -> no scratch).  Replaces Eigen::SelfAdjointEigenSolver
 // at voxel_map.hpp:312 / :1416 / :1525 (result equal up to rounding and eigenvector sign).
+// One Jacobi rotation in the (p,q) plane.  The rotation only has to be ORTHOGONAL to full precision, not optimal: the
+// tangent t is computed in f32 (v_rcp_f32 / v_sqrt_f32, ~1e-7 relative), c = rsqrt(1 + t^2) in f64 (v_rsq_f64 + two
+// Newton steps), s = t c, so c^2 + s^2 = 1 to rounding while the annihilated element is left at ~1e-7 |a_pq| and dies
+// in the next sweep.  Measured on MI355X (K4, one wave per SIMD): the textbook form (f64 div, sqrt, div, sqrt, div per
+// rotation) cost 10.3k cycles per eigen-solve, 45 % of the residual pass.
 __device__ __forceinline__ void jacobi_rot(double &app, double &aqq, double &apq, double &arp, double &arq,
                                            double &v0p, double &v0q, double &v1p, double &v1q, double &v2p, double &v2q,
                                            int sweep) {
   if (apq == 0.0) return;
   const double g = 100.0 * fabs(apq);
-  if (sweep > 3 && fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq)) { apq = 0.0; return; }
-  const double h = aqq - app;
-  double t;
-  if (fabs(h) + g == fabs(h)) {
-    t = apq / h;
-  } else {
-    const double theta = 0.5 * h / apq;
-    t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
-    if (theta < 0.0) t = -t;
-  }
-  const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-  app -= t * apq;
-  aqq += t * apq;
-  apq = 0.0;
-  double x = arp, y = arq;
-  arp = c * x - s * y; arq = s * x + c * y;
-  x = v0p; y = v0q; v0p = c * x - s * y; v0q = s * x + c * y;
-  x = v1p; y = v1q; v1p = c * x - s * y; v1q = s * x + c * y;
-  x = v2p; y = v2q; v2p = c * x - s * y; v2q = s * x + c * y;
+  // an off-diagonal below ulp/200 of both diagonals cannot change them any more: drop it (at any sweep)
+  if (fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq)) { apq = 0.0; return; }
+  // t = sgn(a) b / (|a| + sqrt(a^2 + b^2)),  a = (aqq - app) / 2, b = apq   (the smaller root of t^2 + 2 theta t - 1 = 0);
+  // operands are scaled by the larger magnitude first so that the f32 range cannot over/underflow
+  const double a = 0.5 * (aqq - app);
+  const double inv_scale = __builtin_amdgcn_rcp(fmax(fabs(a), fabs(apq)));   // raw v_rcp_f64: only the ratio a : b matters
+  const float af = (float)(a * inv_scale), bf = (float)(apq * inv_scale);
+  const float tf = bf * __builtin_amdgcn_rcpf(fabsf(af) + __builtin_amdgcn_sqrtf(af * af + bf * bf));   // raw v_sqrt_f32 / v_rcp_f32
+  const double t = (af < 0.0f) ? -(double)tf : (double)tf;
+  const double x = 1.0 + t * t;
+  double c = __builtin_amdgcn_rsq(x);            // ~26 good bits
+  c = c * (1.5 - 0.5 * x * c * c);
+  c = c * (1.5 - 0.5 * x * c * c);
+  const double s = t * c;
+  // A <- J^T A J:  a_pp' = c^2 a_pp - 2 c s a_pq + s^2 a_qq, a_qq' likewise, a_pq' = c s (a_pp - a_qq) + (c^2 - s^2) a_pq
+  const double cc = c * c, ss = s * s, cs = c * s;
+  const double npp = cc * app - 2.0 * cs * apq + ss * aqq;
+  const double nqq = ss * app + 2.0 * cs * apq + cc * aqq;
+  const double npq = cs * (app - aqq) + (cc - ss) * apq;
+  app = npp; aqq = nqq; apq = npq;
+  double x1 = arp, y1 = arq;
+  arp = c * x1 - s * y1; arq = s * x1 + c * y1;
+  x1 = v0p; y1 = v0q; v0p = c * x1 - s * y1; v0q = s * x1 + c * y1;
+  x1 = v1p; y1 = v1q; v1p = c * x1 - s * y1; v1q = s * x1 + c * y1;
+  x1 = v2p; y1 = v2q; v2p = c * x1 - s * y1; v2q = s * x1 + c * y1;
 }
 
 #define VBA_SWAP(a, b) { double _t = a; a = b; b = _t; }
@@ -195,6 +206,8 @@ __global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__r
 //            are masked off, so empty slots still cost 8 B, not 80 B);
 //   then transforms, Jacobi eigen-solve, write-back.  The generic kernel above pays one dependent round trip per frame.
 // Poses are read through uniform (scalar) loads: the frame index is a compile-time constant after unrolling.
+__device__ long long *g_k4_stamps = nullptr;   // diagnostic only (VBA_K4_STAMPS): [wave][t0, loads done, transforms done, eig done, end]
+
 // NB = number of load batches: 1 keeps all 9W cluster scalars in flight (best when the pass is latency-bound, < 1 wave per
 // SIMD); 2 halves the register footprint (<= 128 VGPRs -> 4 waves per SIMD) for passes that fill the chip.
 template <int W, int NB>
@@ -204,6 +217,9 @@ __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *_
   const int v = head + blockIdx.x * 64 + threadIdx.x;
   const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
   double r = 0.0;
+  long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+  long long *stp = g_k4_stamps;
+  if (stp) st0 = clock64();
   if (v < end) {
     double nn[W];
 #pragma unroll
@@ -250,10 +266,12 @@ __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *_
       }
     }
     }
+    if (stp) st1 = clock64();
     const double b0 = s0 / N, b1 = s1 / N, b2 = s2 / N;
     double w0, w1, w2, V[9];
     eig3_sym_dev(P00 / N - b0 * b0, P01 / N - b1 * b0, P02 / N - b2 * b0, P11 / N - b1 * b1, P12 / N - b2 * b1, P22 / N - b2 * b2,
                  w0, w1, w2, V);
+    if (stp) st2 = clock64();
     f.eigval[0 * vs + v] = w0; f.eigval[1 * vs + v] = w1; f.eigval[2 * vs + v] = w2;
 #pragma unroll
     for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + v] = V[k];
@@ -263,6 +281,11 @@ __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *_
   }
   r = wave_sum(r);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
+  if (stp && threadIdx.x == 0 && blockIdx.x < 512) {
+    st3 = clock64();
+    long long *o = stp + (size_t)blockIdx.x * 4;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+  }
 }
 
 // out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 16 outputs x 16 partial groups,

@@ -210,7 +210,27 @@ int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int 
   }
 }
 
+void k4_stamps_dump(vba_ctx *c, int nb, bool before) {
+  static long long *d_st = nullptr;
+  if (before) {
+    if (!d_st) { hipMalloc((void **)&d_st, 512 * 4 * 8); hipMemcpyToSymbol(HIP_SYMBOL(g_k4_stamps), &d_st, sizeof(d_st)); }
+    hipMemsetAsync(d_st, 0, 512 * 4 * 8, c->stream);
+    return;
+  }
+  std::vector<long long> h(512 * 4);
+  hipStreamSynchronize(c->stream);
+  hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+  long long t0 = h[0];
+  const int n = nb < 512 ? nb : 512;
+  for (int b = 0; b < n; b++) if (h[b * 4] && h[b * 4] < t0) t0 = h[b * 4];
+  double a = 0, e = 0, w = 0, last = 0;
+  for (int b = 0; b < n; b++) { a += h[b * 4 + 1] - h[b * 4]; e += h[b * 4 + 2] - h[b * 4 + 1]; w += h[b * 4 + 3] - h[b * 4 + 2]; if (h[b * 4 + 3] - t0 > last) last = h[b * 4 + 3] - t0; }
+  fprintf(stderr, "[k4 stamps] %d waves: loads+transforms %.0f, eigen %.0f, stores+reduce %.0f cycles (mean per wave); last wave ends at %.0f cycles\n", n, a / n, e / n, w / n, last);
+}
+
 void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, int nb) {
+  static const bool want_stamps = getenv("VBA_K4_STAMPS") != nullptr;   // diagnostic switch, off in production
+  if (want_stamps) k4_stamps_dump(c, nb, true);
   // below ~1 wave per SIMD the pass is latency-bound: one load batch; above it, two batches for 4-wave occupancy
   const bool big = nb > 2048;
 #define VBA_RES_CASE(WW) case WW: if (big) hipLaunchKernelGGL((k_residual_w<WW, 3>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); \
@@ -220,6 +240,7 @@ void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, in
     default: hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate);
   }
 #undef VBA_RES_CASE
+  if (want_stamps) k4_stamps_dump(c, nb, false);
 }
 
 // device passes on device-resident poses (gate == nullptr: unconditional)
