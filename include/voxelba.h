@@ -170,6 +170,16 @@ int vba_map_num_slide_roots(vba_ctx *ctx); /* surf_map_slide.size() */
 int vba_map_dump_leaves(vba_ctx *ctx, double *out, int max_leaves);
 
 /* ------------------------------------------------------------------------------------------------
+ * Odometry scan-to-map ("next #1").
+ * bool VOXEL_SLAM::lio_state_estimation(PVecPtr pptr) (VS:962-1098): iterated EKF update of x_curr against the voxel map
+ * with match() (VM:2167-2205) / OctoTree::match (VM:1649-1721).  pnt_body [n][3] and var_body [n][9] are the scan's
+ * body-frame points and covariances (pointVar as produced by var_init, VH:210-234); state [25] and cov [225] = x_curr
+ * (IMUST incl. its 15x15 covariance) in/out; *ok receives the bool result (false = degenerate, VS:1090-1097).
+ * The per-point loop runs on the device, the 15x15 EKF algebra on the host. */
+int vba_odom_lio_state_estimation(vba_ctx *ctx, int n, const double *pnt_body, const double *var_body, double *state,
+                                  double *cov, int *ok);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU: voxels are sharded by root-voxel hash bucket; each rank evaluates its
  * shard and the packed [H | g | r] buffer is summed across ranks (the thread-sum of VM:571-581).
  * The reduction itself is supplied by the host program (torch.distributed/RCCL all_reduce on the

@@ -268,6 +268,39 @@ struct OctoTree {  // VM:1047-1881
       for (int i = 0; i < 8; i++) if (leaves[i] != nullptr) leaves[i]->tras_opt(vox_opt);
     }
   }
+  // VM:1649-1721 (float temporaries at VM:1657-1661 kept)
+  int match(const V3 &wld, Plane *&pla, double &max_prob, const M3 &var_wld, double &sigma_d, OctoTree *&oc) {
+    int flag = 0;
+    if (octo_state == 0) {
+      if (plane.is_plane) {
+        float dis_to_plane = std::fabs(dot(plane.normal, V3(wld - plane.center)));
+        float dis_to_center = V3(plane.center - wld).squaredNorm();
+        float range_dis = (dis_to_center - dis_to_plane * dis_to_plane);
+        if (range_dis <= 3 * 3 * plane.radius) {
+          Mat<1, 6> J_nq;
+          V3 d = wld - plane.center;
+          for (int k = 0; k < 3; k++) { J_nq[k] = d[k]; J_nq[3 + k] = -plane.normal[k]; }
+          double sigma_l = (J_nq * plane.plane_var * J_nq.transpose())[0];
+          sigma_l += dot(plane.normal, V3(var_wld * plane.normal));
+          if (dis_to_plane < 3 * std::sqrt(sigma_l)) {
+            oc = this; sigma_d = sigma_l; pla = &plane;
+            flag = 1;
+          }
+        }
+      }
+    } else {
+      int xyz[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) if (wld[k] > voxel_center[k]) xyz[k] = 1;
+      int leafnum = 4 * xyz[0] + 2 * xyz[1] + xyz[2];
+      if (leaves[leafnum] != nullptr) flag = leaves[leafnum]->match(wld, pla, max_prob, var_wld, sigma_d, oc);
+    }
+    return flag;
+  }
+  bool inside(const V3 &wld) const {  // VM:1836-1848
+    double hl = quater_length * 2;
+    return (wld[0] >= voxel_center[0] - hl && wld[0] <= voxel_center[0] + hl && wld[1] >= voxel_center[1] - hl &&
+            wld[1] <= voxel_center[1] + hl && wld[2] >= voxel_center[2] - hl && wld[2] <= voxel_center[2] + hl);
+  }
   void clear_slwd(std::vector<SlideWindow *> &sws) {  // VM:1856-1880
     if (octo_state != 0) for (int i = 0; i < 8; i++) if (leaves[i] != nullptr) leaves[i]->clear_slwd(sws);
     if (sw != nullptr) { sw->clear(); sws.push_back(sw); sw = nullptr; }
@@ -372,6 +405,100 @@ struct VoxelMapOracle {
   }
   void slide(int mgsize) {  // VS:2014-2019
     for (int i = 0; i < cfg.win_size; i++) { ctx.mp[i] += mgsize; if (ctx.mp[i] >= cfg.win_size) ctx.mp[i] -= cfg.win_size; }
+  }
+
+  // match(feat_map, wld, pla, var_wld, sigma_d, oc)  VM:2167-2205
+  int match(const V3 &wld, Plane *&pla, const M3 &var_wld, double &sigma_d, OctoTree *&oc) {
+    int flag = 0;
+    VOXEL_LOC position = voxel_key(wld, cfg.voxel_size);
+    auto iter = surf_map.find(position);
+    if (iter != surf_map.end()) {
+      double max_prob = 0;
+      flag = iter->second->match(wld, pla, max_prob, var_wld, sigma_d, oc);
+    }
+    return flag;
+  }
+
+  // bool VOXEL_SLAM::lio_state_estimation(PVecPtr pptr)  voxelslam.cpp:962-1098 — iterated EKF scan-to-map update of
+  // x_curr (state + 15x15 cov).  pvec holds body-frame points with body-frame covariance.  trace (optional): per
+  // iteration [match_num, |rot_add|, |tra_add|].
+  bool lio_state_estimation(const PVec &pvec, IMUST &x_curr, std::vector<double> *trace = nullptr) {
+    IMUST x_prop = x_curr;
+    const int num_max_iter = 4;
+    bool EKF_stop_flg = 0, flg_EKF_converged = 0;
+    Mat<15, 15> G, H_T_H, I_STATE = Mat<15, 15>::Identity();
+    int rematch_num = 0, match_num = 0;
+    int psize = (int)pvec.size();
+    std::vector<OctoTree *> octos(psize, nullptr);
+    M3 nnt;
+    Mat<15, 15> cov_inv = inverse_lu<15>(x_curr.cov);
+    for (int iterCount = 0; iterCount < num_max_iter; iterCount++) {
+      M6 HTH; V6 HTz;
+      M3 rot_var = x_curr.cov.block<3, 3>(0, 0);
+      M3 tsl_var = x_curr.cov.block<3, 3>(3, 3);
+      match_num = 0;
+      nnt.setZero();
+      for (int i = 0; i < psize; i++) {
+        const pointVar &pv = pvec[i];
+        M3 phat = hat(pv.pnt);
+        M3 var_world = x_curr.R * pv.var * x_curr.R.transpose() + phat * rot_var * phat.transpose() + tsl_var;
+        V3 wld = x_curr.R * pv.pnt + x_curr.p;
+        double sigma_d = 0;
+        Plane *pla = nullptr;
+        int flag = 0;
+        if (octos[i] != nullptr && octos[i]->inside(wld)) {
+          double max_prob = 0;
+          flag = octos[i]->match(wld, pla, max_prob, var_world, sigma_d, octos[i]);
+        } else {
+          flag = match(wld, pla, var_world, sigma_d, octos[i]);
+        }
+        if (flag) {
+          Plane &pp = *pla;
+          double R_inv = 1.0 / (0.0005 + sigma_d);
+          double resi = dot(pp.normal, V3(wld - pp.center));
+          V6 jac;
+          V3 jr3 = phat * x_curr.R.transpose() * pp.normal;
+          for (int k = 0; k < 3; k++) { jac[k] = jr3[k]; jac[3 + k] = pp.normal[k]; }
+          HTH += (jac * jac.transpose()) * R_inv;
+          HTz -= jac * (R_inv * resi);
+          nnt += pp.normal * pp.normal.transpose();
+          match_num++;
+        }
+      }
+      H_T_H.setZero();  // (the reference only ever writes block (0,0); the rest stays zero)
+      H_T_H.setBlock<6, 6>(0, 0, HTH);
+      Mat<15, 15> K_1 = inverse_lu<15>(H_T_H + cov_inv);
+      Mat<15, 6> K6 = K_1.block<15, 6>(0, 0);
+      G.setZero();
+      G.setBlock<15, 6>(0, 0, K6 * HTH);
+      Mat<15, 1> vec;   // x_prop - x_curr  (IMUST::operator- TL:164-173)
+      vec.setBlock<3, 1>(0, 0, Log(x_curr.R.transpose() * x_prop.R));
+      vec.setBlock<3, 1>(3, 0, x_prop.p - x_curr.p);
+      vec.setBlock<3, 1>(6, 0, x_prop.v - x_curr.v);
+      vec.setBlock<3, 1>(9, 0, x_prop.bg - x_curr.bg);
+      vec.setBlock<3, 1>(12, 0, x_prop.ba - x_curr.ba);
+      Mat<15, 1> solution = K6 * HTz + vec - G.block<15, 6>(0, 0) * vec.block<6, 1>(0, 0);
+      // x_curr += solution  (TL:154-162)
+      x_curr.R = x_curr.R * Exp(solution.block<3, 1>(0, 0));
+      x_curr.p += solution.block<3, 1>(3, 0);
+      x_curr.v += solution.block<3, 1>(6, 0);
+      x_curr.bg += solution.block<3, 1>(9, 0);
+      x_curr.ba += solution.block<3, 1>(12, 0);
+      V3 rot_add = solution.block<3, 1>(0, 0), tra_add = solution.block<3, 1>(3, 0);
+      if (trace) { trace->push_back(match_num); trace->push_back(rot_add.norm()); trace->push_back(tra_add.norm()); }
+      EKF_stop_flg = false;
+      flg_EKF_converged = false;
+      if ((rot_add.norm() * 57.3 < 0.01) && (tra_add.norm() * 100 < 0.015)) flg_EKF_converged = true;
+      if (flg_EKF_converged || ((rematch_num == 0) && (iterCount == num_max_iter - 2))) rematch_num++;
+      if (rematch_num >= 2 || (iterCount == num_max_iter - 1)) {
+        x_curr.cov = (I_STATE - G) * x_curr.cov;
+        EKF_stop_flg = true;
+      }
+      if (EKF_stop_flg) break;
+    }
+    V3 evalue; M3 evec;
+    eig3_sym(nnt, evalue, evec);
+    return !(evalue[0] < 14);
   }
 
   // ---- test dumps

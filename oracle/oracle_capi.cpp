@@ -253,6 +253,23 @@ int vso_map_num_slide_roots(void *m) { return (int)((VoxelMapOracle *)m)->surf_m
 int vso_map_dump_leaves(void *m, double *out, int max_leaves) { return ((VoxelMapOracle *)m)->dump_leaves(out, max_leaves); }
 int vso_map_dump_plane_var(void *m, double *out, int max_leaves) { return ((VoxelMapOracle *)m)->dump_plane_var(out, max_leaves); }
 
+// lio_state_estimation (voxelslam.cpp:962-1098): state[25] + cov[225] in/out; pnt_body [n][3], var_body [n][9];
+// trace (optional) receives rows [match_num, |rot_add|, |tra_add|]; returns the bool result.
+int vso_map_lio_state_estimation(void *m, int n, const double *pnt_body, const double *var_body, double *state, double *cov,
+                                 double *trace, int *n_trace) {
+  VoxelMapOracle *vm = (VoxelMapOracle *)m;
+  PVec pv(n);
+  for (int i = 0; i < n; i++) { pv[i].pnt = v3_from(pnt_body + 3 * i); pv[i].var = m3_from(var_body + 9 * i); }
+  IMUST x = state_from(state);
+  for (int i = 0; i < 225; i++) x.cov[i] = cov[i];
+  std::vector<double> tr;
+  bool ok = vm->lio_state_estimation(pv, x, &tr);
+  state_to(x, state);
+  for (int i = 0; i < 225; i++) cov[i] = x.cov[i];
+  if (trace && n_trace) { for (size_t i = 0; i < tr.size(); i++) trace[i] = tr[i]; *n_trace = (int)tr.size(); }
+  return ok ? 1 : 0;
+}
+
 double vso_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // extern "C"

@@ -220,6 +220,13 @@ class VoxelMap:
     def slide(self, mgsize=1):
         lib().vso_map_slide(self.h, C.c_int(mgsize))
 
+    def lio_state_estimation(self, pnt_body, var_body, state25, cov225):
+        pnt_body = _c(pnt_body); var_body = _c(var_body)
+        state = _c(state25).copy(); cov = _c(cov225).copy()
+        trace = np.zeros(64); ntr = C.c_int(0)
+        ok = lib().vso_map_lio_state_estimation(self.h, C.c_int(len(pnt_body)), _p(pnt_body), _p(var_body), _p(state), _p(cov), _p(trace), C.byref(ntr))
+        return bool(ok), state, cov, trace[:ntr.value].reshape(-1, 3)
+
     def num_roots(self):
         return lib().vso_map_num_roots(self.h)
 

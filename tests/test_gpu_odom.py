@@ -1,0 +1,63 @@
+"""GPU parity test for the odometry scan-to-map update: VOXEL_SLAM::lio_state_estimation
+(voxelslam.cpp:962-1098) with match() / OctoTree::match (voxel_map.hpp:2167-2205, 1649-1721) on the device map vs the CPU
+oracle, after the map's planes were refreshed by a few local-mapping steps (plane_update runs inside margi)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_var(n, seed, scale=0.01):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, scale, (n, 3, 3))
+    return np.ascontiguousarray((A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)).reshape(n, 9))
+
+
+def test_lio_state_estimation_parity(oracle):
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], win_size=4)
+    W = wl.win_size
+    nscan = 8
+    s = synth.make_scans(dataclasses.replace(wl, win_size=nscan))
+    ctx = capi.Context(capi.options_from_workload(wl))
+    om = oracle.VoxelMap(W, wl.voxel_size, wl.max_layer, wl.min_eigen_value, wl.plane_thre, wl.min_point, wl.max_points, 5)
+    of = oracle.Factor(W)
+    x_g, x_o = [], []
+    win_count = 0
+    for k in range(nscan - 1):                       # local mapping on GT poses: builds + refreshes the planes
+        pose = synth.poses_flat(s["R_gt"][k:k + 1], s["p_gt"][k:k + 1])[0]
+        var = _rand_var(len(s["points"][k]), 100 + k)
+        x_g.append(pose.copy()); x_o.append(pose.copy())
+        win_count += 1
+        ctx.cut_voxel(win_count - 1, s["points"][k], x_g[-1], var=var, multi=True)
+        om.cut_voxel(win_count - 1, s["points"][k], x_o[-1], var=var, multi=True)
+        ctx.recut(win_count, np.array(x_g), multi=True)
+        om.recut(win_count, np.array(x_o), of, multi=True)
+        if win_count >= W:
+            ctx.margi(win_count, np.array(x_g), jour=float(k))
+            om.margi(win_count, np.array(x_o), of)
+            ctx.slide(1); om.slide(1)
+            x_g = x_g[1:]; x_o = x_o[1:]
+            win_count -= 1
+    # odometry of the next scan from a perturbed prediction
+    k = nscan - 1
+    rng = np.random.default_rng(5)
+    state = np.zeros(25)
+    state[1:10] = (s["R_gt"][k] @ synth.so3_exp(rng.normal(0, np.radians(0.2), 3))).ravel()
+    state[10:13] = s["p_gt"][k] + rng.normal(0, 0.02, 3)
+    state[13:16] = [1.0, 0.5, 0.0]; state[22:25] = [0, 0, -9.8]
+    cov = np.eye(15) * 1e-4
+    cov[9:, 9:] = np.eye(6) * 1e-5                    # IMUST::setZero (tools.hpp:188-197)
+    pts = s["points"][k]
+    var_b = _rand_var(len(pts), 999, scale=0.005)
+    ok_g, st_g, cov_g = ctx.lio_state_estimation(pts, var_b, state, cov)
+    ok_o, st_o, cov_o, tr = om.lio_state_estimation(pts, var_b, state, cov)
+    assert tr[0, 0] > 2000, "too few matches for a meaningful test: %s" % tr
+    assert ok_g == ok_o
+    assert np.abs(st_g - st_o).max() < 1e-7, np.abs(st_g - st_o).max()
+    assert np.abs(cov_g - cov_o).max() < 1e-9 * np.abs(cov_o).max()
+    # the update pulled the prediction towards the ground truth
+    assert np.abs(st_g[10:13] - s["p_gt"][k]).max() < np.abs(state[10:13] - s["p_gt"][k]).max()

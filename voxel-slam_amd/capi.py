@@ -27,7 +27,7 @@ EXPORTS = [
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
     "vba_map_cut_voxel", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_reset",
-    "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves",
+    "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
     "vba_lm_begin", "vba_lm_refresh_eigen", "vba_lm_iterate", "vba_lm_end",
@@ -286,6 +286,14 @@ class Context:
         if n > 0:
             self.lib.vba_map_dump_leaves(self.h, _p(out), C.c_int(n))
         return out
+
+    # ---- odometry
+    def lio_state_estimation(self, pnt_body, var_body, state25, cov225):
+        """VOXEL_SLAM::lio_state_estimation (voxelslam.cpp:962-1098).  Returns (ok, state, cov)."""
+        pnt_body = _c(pnt_body); var_body = _c(var_body)
+        state = _c(state25).copy(); cov = _c(cov225).copy(); ok = C.c_int(0)
+        self._chk(self.lib.vba_odom_lio_state_estimation(self.h, C.c_int(len(pnt_body)), _p(pnt_body), _p(var_body), _p(state), _p(cov), C.byref(ok)))
+        return bool(ok.value), state, cov
 
     # ---- multi-GPU / timing
     def set_shard(self, rank, n_ranks):

@@ -591,6 +591,116 @@ __global__ void k_margi_clear_points(MapView m, MapParams P, int epoch) {
   if (node >= 0 && m.ndead[m.nroot[node]] == epoch) *pn = -1;
 }
 
+// ------------------------------------------------------------------------------------------------ odometry scan-to-map
+// One EKF iteration's point loop of VOXEL_SLAM::lio_state_estimation (voxelslam.cpp:1004-1052) with match()
+// (voxel_map.hpp:2167-2205) and OctoTree::match (voxel_map.hpp:1649-1721): per point world covariance, root lookup
+// (read-only probe), octant descent, the two 3-sigma gates, then the weighted normal equations
+//   HTH (6x6 sym, 21) | HTz (6) | nnt (3x3 sym, 6) | match_num   = 34 sums per workgroup.
+// The reference's per-point cache octos[i] (voxelslam.cpp:1020) only short-cuts the lookup; the full lookup is done here.
+struct OdomState { double R[9], t[3], rot_var[9], tsl_var[9]; };
+
+__global__ __launch_bounds__(256) void k_odom_match(MapView m, MapParams P, OdomState X, int n, const double *__restrict__ pts,
+                                                    const double *__restrict__ var, double *__restrict__ partial) {
+  __shared__ double red[4][34];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t cp = (size_t)m.cap;
+  double acc[34];
+#pragma unroll
+  for (int k = 0; k < 34; k++) acc[k] = 0.0;
+  if (p < n) {
+    const double bx = pts[3 * (size_t)p], by = pts[3 * (size_t)p + 1], bz = pts[3 * (size_t)p + 2];
+    const double *R = X.R;
+    const double wx = R[0] * bx + R[1] * by + R[2] * bz + X.t[0], wy = R[3] * bx + R[4] * by + R[5] * bz + X.t[1], wz = R[6] * bx + R[7] * by + R[8] * bz + X.t[2];
+    const long long kx = key_axis(wx, P.voxel_size), ky = key_axis(wy, P.voxel_size), kz = key_axis(wz, P.voxel_size);
+    int node = -1;
+    if (!(kx < -KEY_OFF || kx >= KEY_OFF || ky < -KEY_OFF || ky >= KEY_OFF || kz < -KEY_OFF || kz >= KEY_OFF)) {
+      const unsigned long long key = pack_key(kx, ky, kz);
+      unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & m.hmask;
+      for (unsigned int probe = 0; probe <= m.hmask; probe++) {
+        const unsigned long long cur = m.hkeys[h];
+        if (cur == key) { node = m.hvals[h]; break; }
+        if (cur == KEY_EMPTY) break;
+        h = (h + 1) & m.hmask;
+      }
+    }
+    if (node >= 0) {
+      while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, wx, wy, wz);
+      if (m.f_plane[node]) {
+        const double *pl = m.nplane;
+        const double cx = pl[0 * cp + node], cy = pl[1 * cp + node], cz = pl[2 * cp + node];
+        const double nx = pl[3 * cp + node], ny = pl[4 * cp + node], nz = pl[5 * cp + node];
+        const float radius = (float)pl[6 * cp + node];
+        const double dx = wx - cx, dy = wy - cy, dz = wz - cz;
+        const double resi = nx * dx + ny * dy + nz * dz;
+        const float dis_to_plane = (float)fabs(resi);                                  // VM:1657
+        const float dis_to_center = (float)(dx * dx + dy * dy + dz * dz);              // VM:1659
+        const float range_dis = dis_to_center - dis_to_plane * dis_to_plane;           // VM:1661
+        if (range_dis <= 9.0f * radius) {                                              // VM:1664
+          // var_world = R var R^T + phat rot_var phat^T + tsl_var                        voxelslam.cpp:1009
+          double v[9], RV[9], vw[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) v[k] = var[9 * (size_t)p + k];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) RV[3 * r + c] = R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c] + R[3 * r + 2] * v[6 + c];
+          const double ph[9] = {0, -bz, by, bz, 0, -bx, -by, bx, 0};
+          double PR[9];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) PR[3 * r + c] = ph[3 * r] * X.rot_var[c] + ph[3 * r + 1] * X.rot_var[3 + c] + ph[3 * r + 2] * X.rot_var[6 + c];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              vw[3 * r + c] = (RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1] + RV[3 * r + 2] * R[3 * c + 2]) +
+                              (PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1] + PR[3 * r + 2] * ph[3 * c + 2]) + X.tsl_var[3 * r + c];
+          // sigma_l = J plane_var J^T + n^T var_world n,  J = [wld - center, -normal]      VM:1667-1672
+          const double J[6] = {dx, dy, dz, -nx, -ny, -nz};
+          double sigma_l = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            double sr = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) sr += pl[(size_t)(7 + 6 * r + c) * cp + node] * J[c];
+            sigma_l += J[r] * sr;
+          }
+          const double nvec[3] = {nx, ny, nz};
+#pragma unroll
+          for (int r = 0; r < 3; r++) sigma_l += nvec[r] * (vw[3 * r] * nx + vw[3 * r + 1] * ny + vw[3 * r + 2] * nz);
+          if ((double)dis_to_plane < 3.0 * sqrt(sigma_l)) {                             // VM:1675
+            const double Rinv = 1.0 / (0.0005 + sigma_l);                               // voxelslam.cpp:1033
+            // jac = [phat R^T n ; n]                                                     voxelslam.cpp:1039-1040
+            const double a0 = R[0] * nx + R[3] * ny + R[6] * nz, a1 = R[1] * nx + R[4] * ny + R[7] * nz, a2 = R[2] * nx + R[5] * ny + R[8] * nz;
+            const double jac[6] = {by * a2 - bz * a1, bz * a0 - bx * a2, bx * a1 - by * a0, nx, ny, nz};
+            int idx = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+              for (int c = r; c < 6; c++) acc[idx++] = Rinv * jac[r] * jac[c];           // HTH upper triangle
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[21 + r] = -Rinv * jac[r] * resi;             // HTz
+            acc[27] = nx * nx; acc[28] = nx * ny; acc[29] = nx * nz; acc[30] = ny * ny; acc[31] = ny * nz; acc[32] = nz * nz;   // nnt
+            acc[33] = 1.0;                                                               // match_num
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 34; k++) {
+    double x = acc[k];
+    for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
+    acc[k] = x;
+  }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 34; k++) red[threadIdx.x >> 6][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 34) partial[(size_t)blockIdx.x * 34 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------------ dumps
 __global__ void k_dump_leaves(MapView m, double *out, int max_leaves) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1064,6 +1174,20 @@ inline int map_dump_leaves(MapStore &s, hipStream_t st, double *out, int max_lea
     hipFree(d_out);
   }
   return n;
+}
+
+// One scan-to-map accumulation: out34 (host) = [HTH upper (21) | HTz (6) | nnt upper (6) | match_num]
+inline int map_odom_accumulate(MapStore &s, hipStream_t st, const OdomState &X, int n, const double *d_pts, const double *d_var,
+                               double *d_partial, double *d_out34, double *out34, std::string &err) {
+  if (!s.allocated) { for (int k = 0; k < 34; k++) out34[k] = 0.0; return VBA_OK; }
+  const MapParams P = map_params(s);
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_odom_match, dim3(nb), dim3(256), 0, st, s.v, P, X, n, d_pts, d_var, d_partial);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, st, d_partial, nb, 34, d_out34, (const int *)nullptr);
+  MAPCHK(hipGetLastError());
+  MAPCHK(hipMemcpyAsync(out34, d_out34, 34 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MAPCHK(hipStreamSynchronize(st));
+  return VBA_OK;
 }
 
 }  // namespace vba

@@ -881,6 +881,103 @@ int vba_map_slide(vba_ctx *c, int mgsize) { return map_slide(c->map, mgsize); }
 int vba_map_reset(vba_ctx *c) { return map_reset(c->map, c->stream, c->err); }
 int vba_map_num_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, false); }
 int vba_map_num_slide_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, true); }
+// ---------------------------------------------------------------- odometry scan-to-map (VS:962-1098)
+int vba_odom_lio_state_estimation(vba_ctx *c, int n, const double *pnt_body, const double *var_body, double *state, double *cov, int *ok) {
+  if (n < 0 || (n > 0 && (!pnt_body || !var_body)) || !state || !cov) return VBA_ERR_BAD_ARG;
+  const int DIM = VBA_DIM;
+  // stage the scan once: [pts n*3 | var n*9 | partial nb*34 | out 34]
+  const int nb = (n + 255) / 256;
+  const size_t bytes = ((size_t)n * 12 + (size_t)nb * 34 + 64) * sizeof(double);
+  int st = ensure_stage(c, bytes);
+  if (st) return st;
+  double *d_pts = (double *)c->d_stage, *d_var = d_pts + (size_t)n * 3, *d_part = d_var + (size_t)n * 9, *d_o34 = d_part + (size_t)nb * 34;
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(d_pts, pnt_body, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_var, var_body, (size_t)n * 9 * sizeof(double), hipMemcpyDefault, c->stream));
+  }
+  vbh::State x_curr, x_prop;
+  std::memcpy(&x_curr, state, sizeof(x_curr));
+  x_prop = x_curr;                                                         // VS:965
+  std::vector<double> P(cov, cov + 225), cov_inv(225);
+  vbh::inverse_pplu(P.data(), cov_inv.data(), DIM);                        // VS:987
+  const int num_max_iter = 4;
+  int rematch_num = 0;
+  double nnt[9] = {0};
+  double G[225];
+  for (int iter = 0; iter < num_max_iter; iter++) {
+    OdomState X;
+    std::memcpy(X.R, x_curr.R, sizeof(X.R)); std::memcpy(X.t, x_curr.p, sizeof(X.t));
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { X.rot_var[3 * r + k] = P[r * DIM + k]; X.tsl_var[3 * r + k] = P[(3 + r) * DIM + 3 + k]; }   // VS:1000-1001
+    double s34[34];
+    if (n > 0) { st = map_odom_accumulate(c->map, c->stream, X, n, d_pts, d_var, d_part, d_o34, s34, c->err); if (st) return st; }
+    else std::memset(s34, 0, sizeof(s34));
+    double HTH[36], HTz[6];
+    { int idx = 0; for (int r = 0; r < 6; r++) for (int k = r; k < 6; k++) { HTH[r * 6 + k] = s34[idx]; HTH[k * 6 + r] = s34[idx]; idx++; } }
+    for (int r = 0; r < 6; r++) HTz[r] = s34[21 + r];
+    nnt[0] = s34[27]; nnt[1] = nnt[3] = s34[28]; nnt[2] = nnt[6] = s34[29]; nnt[4] = s34[30]; nnt[5] = nnt[7] = s34[31]; nnt[8] = s34[32];
+    // K_1 = (H_T_H + cov_inv)^-1 ; G(:,0:6) = K_1(:,0:6) HTH ; solution = K_1(:,0:6) HTz + vec - G(:,0:6) vec(0:6)      VS:1056-1060
+    std::vector<double> A(cov_inv), K1(225);
+    for (int r = 0; r < 6; r++) for (int k = 0; k < 6; k++) A[r * DIM + k] += HTH[r * 6 + k];
+    vbh::inverse_pplu(A.data(), K1.data(), DIM);
+    std::memset(G, 0, sizeof(G));
+    for (int r = 0; r < DIM; r++)
+      for (int k = 0; k < 6; k++) { double sacc = 0; for (int j = 0; j < 6; j++) sacc += K1[r * DIM + j] * HTH[j * 6 + k]; G[r * DIM + k] = sacc; }
+    double vec[15], RtR[9], lg[3];
+    vbh::m3_Tmul(x_curr.R, x_prop.R, RtR);                                 // x_prop - x_curr: Log(b.R^T this.R)  TL:164-173
+    vbh::so3_log(RtR, lg);
+    for (int k = 0; k < 3; k++) { vec[k] = lg[k]; vec[3 + k] = x_prop.p[k] - x_curr.p[k]; vec[6 + k] = x_prop.v[k] - x_curr.v[k]; vec[9 + k] = x_prop.bg[k] - x_curr.bg[k]; vec[12 + k] = x_prop.ba[k] - x_curr.ba[k]; }
+    double sol[15];
+    for (int r = 0; r < DIM; r++) {
+      double a = 0, b = 0;
+      for (int j = 0; j < 6; j++) { a += K1[r * DIM + j] * HTz[j]; b += G[r * DIM + j] * vec[j]; }
+      sol[r] = a + vec[r] - b;
+    }
+    double E[9], Rn[9];                                                    // x_curr += solution  TL:154-162
+    vbh::so3_exp(sol, E);
+    vbh::m3_mul(x_curr.R, E, Rn);
+    std::memcpy(x_curr.R, Rn, sizeof(Rn));
+    for (int k = 0; k < 3; k++) { x_curr.p[k] += sol[3 + k]; x_curr.v[k] += sol[6 + k]; x_curr.bg[k] += sol[9 + k]; x_curr.ba[k] += sol[12 + k]; }
+    const double rot_add = vbh::norm3(sol), tra_add = vbh::norm3(sol + 3);
+    const bool converged = (rot_add * 57.3 < 0.01) && (tra_add * 100 < 0.015);     // VS:1072
+    if (converged || ((rematch_num == 0) && (iter == num_max_iter - 2))) rematch_num++;   // VS:1076-1079
+    if (rematch_num >= 2 || (iter == num_max_iter - 1)) {                  // x_curr.cov = (I - G) cov   VS:1082-1086
+      std::vector<double> IG(225), Pn(225);
+      for (int r = 0; r < DIM; r++) for (int k = 0; k < DIM; k++) IG[r * DIM + k] = (r == k ? 1.0 : 0.0) - G[r * DIM + k];
+      vbh::mat_mul(IG.data(), P.data(), Pn.data(), DIM, DIM, DIM);
+      P = Pn;
+      break;
+    }
+  }
+  std::memcpy(state, &x_curr, sizeof(x_curr));
+  std::memcpy(cov, P.data(), 225 * sizeof(double));
+  if (ok) {
+    // SelfAdjointEigenSolver(nnt).eigenvalues()[0] < 14 -> false  (VS:1090-1097); closed form is not needed here: Jacobi on host
+    double a[3][3] = {{nnt[0], nnt[1], nnt[2]}, {nnt[3], nnt[4], nnt[5]}, {nnt[6], nnt[7], nnt[8]}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+      const double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+      if (off == 0.0) break;
+      for (int p = 0; p < 2; p++)
+        for (int q = p + 1; q < 3; q++) {
+          if (a[p][q] == 0.0) continue;
+          const double theta = 0.5 * (a[q][q] - a[p][p]) / a[p][q];
+          double t = 1.0 / (std::fabs(theta) + std::sqrt(1.0 + theta * theta));
+          if (theta < 0) t = -t;
+          const double cth = 1.0 / std::sqrt(1 + t * t), sth = t * cth, apq = a[p][q];
+          const int r = 3 - p - q;
+          const double arp = a[r][p], arq = a[r][q];
+          a[p][p] -= t * apq; a[q][q] += t * apq; a[p][q] = a[q][p] = 0.0;
+          a[r][p] = a[p][r] = cth * arp - sth * arq; a[r][q] = a[q][r] = sth * arp + cth * arq;
+          if (std::fabs(a[r][p]) < 1e-300) a[r][p] = a[p][r] = 0.0;
+          if (std::fabs(a[r][q]) < 1e-300) a[r][q] = a[q][r] = 0.0;
+        }
+      if (off < 1e-14 * (std::fabs(a[0][0]) + std::fabs(a[1][1]) + std::fabs(a[2][2]))) break;
+    }
+    const double emin = std::min(a[0][0], std::min(a[1][1], a[2][2]));
+    *ok = (emin < 14) ? 0 : 1;
+  }
+  return VBA_OK;
+}
+
 int vba_map_dump_leaves(vba_ctx *c, double *out, int max_leaves) { return map_dump_leaves(c->map, c->stream, out, max_leaves, c->err); }
 
 }  // extern "C"
