@@ -160,6 +160,9 @@ int vba_map_recut(vba_ctx *ctx, int win_count, const double *poses, int multi);
 int vba_map_margi(vba_ctx *ctx, int win_count, const double *poses, double jour);
 /* Ring-map rotation mp[i] = (mp[i] + mgsize) mod W (VS:2014-2019). */
 int vba_map_slide(vba_ctx *ctx, int mgsize);
+/* "Release the features not used for a long time" (VS:1800-1823): roots with int(jour - root.jour) >= dist (700 in
+ * the reference) leave surf_map with their subtrees. */
+int vba_map_prune(vba_ctx *ctx, double jour, int dist);
 /* Destroys the map (system_reset / motion_init teardown, VS:650-661). */
 int vba_map_reset(vba_ctx *ctx);
 int vba_map_num_roots(vba_ctx *ctx);       /* surf_map.size() */

@@ -393,15 +393,28 @@ struct VoxelMapOracle {
       for (auto &kv : surf_map) { kv.second->recut(win_count, xs, sws); kv.second->tras_opt(voxopt); }
     }
   }
-  bool multi_margi(int win_count, std::vector<IMUST> &xs, LidarFactor &voxopt) {  // VS:1590-1679
+  bool multi_margi(int win_count, std::vector<IMUST> &xs, LidarFactor &voxopt, double jour = 0) {  // VS:1590-1679
     if ((int)surf_map_slide.size() < cfg.thread_num) return true;
     bool ok = true;
+    for (auto &kv : surf_map_slide) kv.second->jour = jour;   // VS:1628
     for (auto &kv : surf_map_slide) ok = kv.second->margi(win_count, 1, xs, voxopt) && ok;
     for (auto iter = surf_map_slide.begin(); iter != surf_map_slide.end();) {
       if (iter->second->isexist) iter++;
       else { iter->second->clear_slwd(sws); surf_map_slide.erase(iter++); }
     }
     return ok;
+  }
+  void prune(double jour, int dist = 700) {  // voxelslam.cpp:1800-1823
+    for (auto iter = surf_map.begin(); iter != surf_map.end();) {
+      int dis = jour - iter->second->jour;
+      if (dis < dist) iter++;
+      else {
+        surf_map_slide.erase(iter->first);   // (never the case in the reference: sliding-map roots carry a fresh jour)
+        iter->second->clear_slwd(sws);
+        delete iter->second;
+        surf_map.erase(iter++);
+      }
+    }
   }
   void slide(int mgsize) {  // VS:2014-2019
     for (int i = 0; i < cfg.win_size; i++) { ctx.mp[i] += mgsize; if (ctx.mp[i] >= cfg.win_size) ctx.mp[i] -= cfg.win_size; }

@@ -240,11 +240,12 @@ void vso_map_recut(void *m, int win_count, const double *poses, void *fh, int mu
   f->clear(); f->win_size = vm->cfg.win_size;
   vm->recut_all(win_count, xs, *f, multi != 0);
 }
-void vso_map_margi(void *m, int win_count, const double *poses, void *fh) {
+void vso_map_margi(void *m, int win_count, const double *poses, void *fh, double jour) {
   VoxelMapOracle *vm = (VoxelMapOracle *)m;
   std::vector<IMUST> xs = poses_to_states(poses, win_count);
-  vm->multi_margi(win_count, xs, *(LidarFactor *)fh);
+  vm->multi_margi(win_count, xs, *(LidarFactor *)fh, jour);
 }
+void vso_map_prune(void *m, double jour, int dist) { ((VoxelMapOracle *)m)->prune(jour, dist); }
 void vso_map_slide(void *m, int mgsize) { ((VoxelMapOracle *)m)->slide(mgsize); }
 int vso_map_num_roots(void *m) { return (int)((VoxelMapOracle *)m)->surf_map.size(); }
 int vso_map_num_slide_roots(void *m) { return (int)((VoxelMapOracle *)m)->surf_map_slide.size(); }

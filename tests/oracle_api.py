@@ -213,12 +213,15 @@ class VoxelMap:
         poses = _c(poses)
         lib().vso_map_recut(self.h, C.c_int(win_count), _p(poses), factor.h, C.c_int(int(multi)))
 
-    def margi(self, win_count, poses, factor):
+    def margi(self, win_count, poses, factor, jour=0.0):
         poses = _c(poses)
-        lib().vso_map_margi(self.h, C.c_int(win_count), _p(poses), factor.h)
+        lib().vso_map_margi(self.h, C.c_int(win_count), _p(poses), factor.h, C.c_double(jour))
 
     def slide(self, mgsize=1):
         lib().vso_map_slide(self.h, C.c_int(mgsize))
+
+    def prune(self, jour, dist=700):
+        lib().vso_map_prune(self.h, C.c_double(jour), C.c_int(dist))
 
     def lio_state_estimation(self, pnt_body, var_body, state25, cov225):
         pnt_body = _c(pnt_body); var_body = _c(var_body)

@@ -29,6 +29,7 @@ __host__ __device__ inline uint64_t shard_bucket(int64_t kx, int64_t ky, int64_t
 }
 
 static constexpr unsigned long long KEY_EMPTY = ~0ull;
+static constexpr unsigned long long KEY_TOMB = ~0ull - 1;   // erased root (map pruning): probes walk past it
 static constexpr int KEY_BITS = 21, KEY_OFF = 1 << 20;
 
 __host__ __device__ inline unsigned long long pack_key(long long kx, long long ky, long long kz) {
@@ -275,6 +276,7 @@ __global__ void k_fix_accum(MapView m, MapParams P, int base, int n) {
 
 // ------------------------------------------------------------------------------------------------ K2: recut
 __device__ __forceinline__ bool in_scope(const MapView &m, const MapParams &P, int node, int multi) {
+  if (m.nlayer[node] < 0) return false;   // pruned
   if (!multi) return true;
   return m.f_slide[m.nroot[node]] != 0;
 }
@@ -591,6 +593,45 @@ __global__ void k_margi_clear_points(MapView m, MapParams P, int epoch) {
   if (node >= 0 && m.ndead[m.nroot[node]] == epoch) *pn = -1;
 }
 
+// ------------------------------------------------------------------------------------------------ pruning
+// "release the features not used for a long time" (voxelslam.cpp:1800-1823): roots with int(jour - root.jour) >= dist
+// leave surf_map together with their subtrees.  The hash slot becomes a tombstone; node storage is not recycled (a
+// later compaction pass can do that), the subtree is only made unreachable and its fixed points are dropped.
+__global__ void k_prune_roots(MapView m, double jour, int dist, int epoch) {
+  const unsigned int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h > m.hmask) return;
+  const unsigned long long key = m.hkeys[h];
+  if (key == KEY_EMPTY || key == KEY_TOMB) return;
+  const int root = m.hvals[h];
+  if (root < 0) return;
+  const int dis = (int)(jour - m.njour[root]);
+  if (dis < dist) return;
+  m.hkeys[h] = KEY_TOMB; m.hvals[h] = -1;
+  m.ndead[root] = epoch;
+  atomicSub(&m.cnt[CNT_ROOTS], 1);
+  if (m.f_slide[root]) { m.f_slide[root] = 0; atomicSub(&m.cnt[CNT_SLIDE], 1); }
+}
+__global__ void k_prune_nodes(MapView m, int epoch) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nlayer[id] < 0 || m.ndead[m.nroot[id]] != epoch) return;
+  if (m.nroot[id] != id) m.nlayer[id] = -1;     // children first become unreachable ...
+}
+__global__ void k_prune_finish(MapView m, int epoch) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nroot[id] == id && m.ndead[id] == epoch) m.nlayer[id] = -1;   // ... then the roots themselves
+}
+__global__ void k_prune_fix(MapView m) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = m.cnt[CNT_FIX] < m.cap_fix ? m.cnt[CNT_FIX] : m.cap_fix;
+  if (q >= nf) return;
+  const int node = m.fnode[q];
+  if (node >= 0 && m.nlayer[node] < 0) m.fnode[q] = -1;
+}
+
 // ------------------------------------------------------------------------------------------------ odometry scan-to-map
 // One EKF iteration's point loop of VOXEL_SLAM::lio_state_estimation (voxelslam.cpp:1004-1052) with match()
 // (voxel_map.hpp:2167-2205) and OctoTree::match (voxel_map.hpp:1649-1721): per point world covariance, root lookup
@@ -706,7 +747,7 @@ __global__ void k_dump_leaves(MapView m, double *out, int max_leaves) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
-  if (m.nstate[id] != 0) return;
+  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return;  // internal node, or pruned
   if (m.nlayer[id] > 0 && !m.f_touched[id]) return;   // never-touched octants do not exist in the reference tree
   const int i = atomicAdd(&m.cnt[CNT_LEAVES], 1);
   if (i >= max_leaves) return;
@@ -729,7 +770,7 @@ __global__ void k_rehash(const unsigned long long *okeys, const int *ovals, unsi
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > omask) return;
   const unsigned long long key = okeys[i];
-  if (key == KEY_EMPTY) return;
+  if (key == KEY_EMPTY || key == KEY_TOMB) return;
   unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & nmask;
   while (true) {
     if (atomicCAS(&nkeys[h], KEY_EMPTY, key) == KEY_EMPTY) { nvals[h] = ovals[i]; return; }
@@ -1174,6 +1215,21 @@ inline int map_dump_leaves(MapStore &s, hipStream_t st, double *out, int max_lea
     hipFree(d_out);
   }
   return n;
+}
+
+inline int map_prune(MapStore &s, hipStream_t st, double jour, int dist, std::string &err) {
+  if (!s.allocated) return VBA_OK;
+  int r = map_read_counters(s, st, err);
+  if (r) return r;
+  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+  if (nn == 0) return VBA_OK;
+  s.epoch++;
+  hipLaunchKernelGGL(k_prune_roots, dim3((s.hcap + 255) / 256), dim3(256), 0, st, s.v, jour, dist, s.epoch);
+  hipLaunchKernelGGL(k_prune_nodes, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, s.epoch);
+  hipLaunchKernelGGL(k_prune_finish, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, s.epoch);
+  if (s.h_cnt[CNT_FIX] > 0) hipLaunchKernelGGL(k_prune_fix, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v);
+  MAPCHK(hipGetLastError());
+  return map_read_counters(s, st, err);
 }
 
 // One scan-to-map accumulation: out34 (host) = [HTH upper (21) | HTz (6) | nnt upper (6) | match_num]

@@ -878,6 +878,7 @@ int vba_map_margi(vba_ctx *c, int win_count, const double *poses, double jour) {
   return st;
 }
 int vba_map_slide(vba_ctx *c, int mgsize) { return map_slide(c->map, mgsize); }
+int vba_map_prune(vba_ctx *c, double jour, int dist) { return map_prune(c->map, c->stream, jour, dist, c->err); }
 int vba_map_reset(vba_ctx *c) { return map_reset(c->map, c->stream, c->err); }
 int vba_map_num_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, false); }
 int vba_map_num_slide_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, true); }
