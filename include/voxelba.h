@@ -148,6 +148,15 @@ int vba_imu_give_evaluate(const double *imu_pre, const double *state1, const dou
  * pnt_body / var may point to HOST or DEVICE (HBM) memory; device buffers are consumed in place. */
 int vba_map_cut_voxel(vba_ctx *ctx, int win_count, int n, const double *pnt_body, const double *var,
                       const double *pose, int multi);
+/* pvec_update (VH:242-265) fused with cut_voxel[_multi]: var_body [n][9] is the BODY-frame covariance of the scan's
+ * points (from var_init); the world-frame covariance var = R var R^T + phat rot_var phat^T + tsl_var is formed on the
+ * device from the scan state's covariance cov [225] (x_curr.cov: rot block (0,0), translation block (3,3)). */
+int vba_map_pvec_update_cut_voxel(vba_ctx *ctx, int win_count, int n, const double *pnt_body, const double *var_body,
+                                  const double *pose, const double *cov, int multi);
+/* var_init (VH:210-234) = calcBodyVar (VH:180-200) + extrinsic ext_pose [12]: pnt_in [n][3] -> pnt_out [n][3],
+ * var_out [n][9] (host buffers; pnt_out may alias pnt_in). */
+int vba_scan_var_init(vba_ctx *ctx, int n, const double *pnt_in, const double *ext_pose, double dept_err, double beam_err,
+                      double *pnt_out, double *var_out);
 /* cut_voxel(feat_map, PVec&, wdsize, jour) for fixed (already-world) points (VM:2108-2152). */
 int vba_map_cut_voxel_fix(vba_ctx *ctx, int n, const double *pnt_world, double jour);
 /* multi_recut (VS:1682-1737) when multi != 0, or the loop "recut + tras_opt over surf_map" of motion_init

@@ -74,6 +74,43 @@ inline void Bf_var(const pointVar &pv, Mat<9, 9> &bcov, const V3 &vec) {  // VM:
   bcov.setBlock<3, 3>(6, 6, pv.var);
 }
 
+// calcBodyVar voxelslam.hpp:180-200 (float narrowing of range / range_var kept).  DEG2RAD is PCL's macro
+// (pcl/pcl_macros.h, PCL 1.10 per README.md:27; the header is not in the reference tree): ((x) * 0.017453293).
+inline void calcBodyVar(V3 &pb, const float range_inc, const float degree_inc, M3 &var) {
+  if (pb[2] == 0) pb[2] = 0.0001;
+  float range = std::sqrt(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]);
+  float range_var = range_inc * range_inc;
+  const double dv = std::pow(std::sin((degree_inc) * 0.017453293), 2);
+  V3 direction = pb / pb.norm();
+  M3 direction_hat = hat(direction);
+  V3 b1 = v3(1, 1, -(direction[0] + direction[1]) / direction[2]);
+  b1 = b1 / b1.norm();
+  V3 b2 = cross(b1, direction);
+  b2 = b2 / b2.norm();
+  Mat<3, 2> N;
+  for (int r = 0; r < 3; r++) { N(r, 0) = b1[r]; N(r, 1) = b2[r]; }
+  Mat<3, 2> A = (direction_hat * N) * (double)range;
+  Mat<2, 2> dvar; dvar(0, 0) = dv; dvar(1, 1) = dv;
+  var = (direction * direction.transpose()) * (double)range_var + A * dvar * A.transpose();
+}
+// var_init voxelslam.hpp:210-234: body covariance, then point and covariance moved by the extrinsic
+inline void var_init(const M3 &extR, const V3 &extp, PVec &pv, double dept_err, double beam_err) {
+  for (pointVar &q : pv) {
+    calcBodyVar(q.pnt, dept_err, beam_err, q.var);
+    q.pnt = extR * q.pnt + extp;
+    q.var = extR * q.var * extR.transpose();
+  }
+}
+// pvec_update voxelslam.hpp:242-265: var becomes world-frame, pnt stays body-frame, pwld = R p + t
+inline void pvec_update(PVec &pv, const IMUST &x, std::vector<V3> &pwld) {
+  M3 rot_var = x.cov.block<3, 3>(0, 0), tsl_var = x.cov.block<3, 3>(3, 3);
+  for (pointVar &q : pv) {
+    M3 phat = hat(q.pnt);
+    q.var = x.R * q.var * x.R.transpose() + phat * rot_var * phat.transpose() + tsl_var;
+    pwld.push_back(x.R * q.pnt + x.p);
+  }
+}
+
 struct SlideWindow {  // VM:1009-1042
   std::vector<PVec> points;
   std::vector<PointCluster> pcrs_local;

@@ -271,6 +271,24 @@ int vso_map_lio_state_estimation(void *m, int n, const double *pnt_body, const d
   return ok ? 1 : 0;
 }
 
+// var_init (voxelslam.hpp:210-234): pnt [n][3] in/out, var [n][9] out
+void vso_var_init(int n, double *pnt, const double *ext_pose, double dept_err, double beam_err, double *var) {
+  PVec pv(n);
+  for (int i = 0; i < n; i++) pv[i].pnt = v3_from(pnt + 3 * i);
+  var_init(m3_from(ext_pose), v3_from(ext_pose + 9), pv, dept_err, beam_err);
+  for (int i = 0; i < n; i++) { v3_to(pv[i].pnt, pnt + 3 * i); m3_to(pv[i].var, var + 9 * i); }
+}
+// pvec_update (voxelslam.hpp:242-265): var [n][9] in/out (body -> world), pwld [n][3] out
+void vso_pvec_update(int n, const double *pnt, double *var, const double *state, const double *cov, double *pwld) {
+  PVec pv(n);
+  for (int i = 0; i < n; i++) { pv[i].pnt = v3_from(pnt + 3 * i); pv[i].var = m3_from(var + 9 * i); }
+  IMUST x = state_from(state);
+  for (int i = 0; i < 225; i++) x.cov[i] = cov[i];
+  std::vector<V3> pw;
+  pvec_update(pv, x, pw);
+  for (int i = 0; i < n; i++) { m3_to(pv[i].var, var + 9 * i); v3_to(pw[i], pwld + 3 * i); }
+}
+
 double vso_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // extern "C"

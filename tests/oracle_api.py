@@ -177,6 +177,18 @@ def imu_give_evaluate(imu, st1, st2, with_g=False, jac=True):
     return r, jtj, gg
 
 
+def var_init(pnt, ext_pose12, dept_err, beam_err):
+    pnt = _c(pnt).copy(); ext = _c(ext_pose12); var = np.empty((len(pnt), 9))
+    lib().vso_var_init(C.c_int(len(pnt)), _p(pnt), _p(ext), C.c_double(dept_err), C.c_double(beam_err), _p(var))
+    return pnt, var
+
+
+def pvec_update(pnt, var, state25, cov225):
+    pnt = _c(pnt); var = _c(var).copy(); st = _c(state25); cov = _c(cov225); pw = np.empty((len(pnt), 3))
+    lib().vso_pvec_update(C.c_int(len(pnt)), _p(pnt), _p(var), _p(st), _p(cov), _p(pw))
+    return var, pw
+
+
 def map_key(voxel_size, pw):
     pw = _c(pw); k = (C.c_longlong * 3)()
     lib().vso_map_key(C.c_double(voxel_size), _p(pw), k)

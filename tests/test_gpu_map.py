@@ -227,3 +227,43 @@ def test_prune_parity(capi, oracle, synth):
     ctx.cut_voxel(W - 1, more, poses[1], multi=True); om.cut_voxel(W - 1, more, poses[1], multi=True)
     assert ctx.num_roots() == om.num_roots()
     _compare_leaves(ctx.dump_leaves(), om.dump_leaves(), check_plane=False)
+
+
+def test_var_init_and_pvec_update_parity(capi, oracle, synth):
+    """Scan pre-processing that feeds the path: var_init / calcBodyVar (voxelslam.hpp:180-234) and
+    pvec_update (voxelslam.hpp:242-265, fused into the insert) against the oracle restatements."""
+    wl = synth.CONFIGS["room20k_w4"]
+    s = synth.make_scans(wl)
+    W = wl.win_size
+    ctx = capi.Context(_opts(capi, wl))
+    pts = s["points"][0].copy()
+    pts[5, 2] = 0.0                                            # exercises the pb[2] == 0 branch (voxelslam.hpp:182-183)
+    ext = np.concatenate([synth.so3_exp(np.array([0.01, -0.02, 0.03])).ravel(), [0.05, -0.02, 0.1]])
+    pg, vg = ctx.var_init(pts, ext, wl.dept_err, wl.beam_err)
+    po, vo = oracle.var_init(pts, ext, wl.dept_err, wl.beam_err)
+    assert np.abs(pg - po).max() < 1e-12
+    assert np.abs(vg - vo).max() < 1e-12 * np.abs(vo).max()
+    # pvec_update + cut_voxel: the accumulated cov_add / plane_var must match an oracle that applies pvec_update first
+    rng = np.random.default_rng(3)
+    A = rng.normal(0, 0.01, (15, 15)); cov = A @ A.T + np.eye(15) * 1e-4
+    om = _omap(oracle, wl)
+    for i in range(W):
+        pose = synth.poses_flat(s["R_gt"][i:i + 1], s["p_gt"][i:i + 1])[0]
+        state = np.zeros(25); state[1:10] = pose[:9]; state[10:13] = pose[9:]
+        p_i, v_i = oracle.var_init(s["points"][i], ext, wl.dept_err, wl.beam_err)
+        v_w, _ = oracle.pvec_update(p_i, v_i, state, cov)
+        om.cut_voxel(i, p_i, pose, var=v_w, multi=True)
+        ctx.pvec_update_cut_voxel(i, p_i, v_i, pose, cov, multi=True)
+    poses = synth.poses_flat(s["R_gt"], s["p_gt"])
+    of = oracle.Factor(W)
+    ctx.recut(W, poses, multi=True); om.recut(W, poses, of, multi=True)
+    ctx.margi(W, poses, jour=1.0); om.margi(W, poses, of, jour=1.0)      # plane_update consumes cov_add
+    gd, od = ctx.dump_leaves(), om.dump_leaves()
+    _compare_leaves(gd, od)
+    g, o = _leaf_table(gd), _leaf_table(od)
+    npl = 0
+    for key, ro in o.items():
+        if ro[7] and np.abs(ro[35:38]).max() > 0:
+            assert abs(g[key][38] - ro[38]) < 1e-6 * max(1e-3, abs(ro[38]))
+            npl += 1
+    assert npl > 20

@@ -26,7 +26,7 @@ EXPORTS = [
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
-    "vba_map_cut_voxel", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
+    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
@@ -255,6 +255,19 @@ class Context:
         pnt_body = _c(pnt_body); pose12 = _c(pose12)
         v = _c(var) if var is not None else None
         self._chk(self.lib.vba_map_cut_voxel(self.h, C.c_int(win_count), C.c_int(len(pnt_body)), _p(pnt_body), _p(v), _p(pose12), C.c_int(int(multi))))
+
+    def pvec_update_cut_voxel(self, win_count, pnt_body, var_body, pose12, cov225, multi=False):
+        """pvec_update (voxelslam.hpp:242-265) + cut_voxel[_multi], fused on the device."""
+        pnt_body = _c(pnt_body); var_body = _c(var_body); pose12 = _c(pose12); cov = _c(cov225)
+        self._chk(self.lib.vba_map_pvec_update_cut_voxel(self.h, C.c_int(win_count), C.c_int(len(pnt_body)), _p(pnt_body), _p(var_body),
+                                                         _p(pose12), _p(cov), C.c_int(int(multi))))
+
+    def var_init(self, pnt, ext_pose12, dept_err, beam_err):
+        """var_init (voxelslam.hpp:210-234): returns (pnt_out, var_out)."""
+        pnt = _c(pnt); ext = _c(ext_pose12)
+        po = np.empty_like(pnt); var = np.empty((len(pnt), 9))
+        self._chk(self.lib.vba_scan_var_init(self.h, C.c_int(len(pnt)), _p(pnt), _p(ext), C.c_double(dept_err), C.c_double(beam_err), _p(po), _p(var)))
+        return po, var
 
     def cut_voxel_fix(self, pnt_world, jour=0.0):
         pnt_world = _c(pnt_world)

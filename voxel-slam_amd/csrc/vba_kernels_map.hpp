@@ -777,6 +777,81 @@ __global__ void k_rehash(const unsigned long long *okeys, const int *ovals, unsi
     h = (h + 1) & nmask;
   }
 }
+// var_init (voxelslam.hpp:210-234) = calcBodyVar (voxelslam.hpp:180-200) + extrinsic: one thread per point.
+// DEG2RAD is PCL's macro ((x) * 0.017453293), see oracle/map_oracle.hpp.
+__global__ void k_var_init(int n, const double *__restrict__ pin, double *__restrict__ pout, double *__restrict__ var, const double *__restrict__ ext,
+                           float range_inc, float degree_inc) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  double x = pin[3 * (size_t)p], y = pin[3 * (size_t)p + 1], z = pin[3 * (size_t)p + 2];
+  if (z == 0) z = 0.0001;
+  const float range = (float)sqrt(x * x + y * y + z * z);
+  const float range_var = range_inc * range_inc;
+  const double sn = sin((degree_inc) * 0.017453293), dv = sn * sn;
+  const double nrm = sqrt(x * x + y * y + z * z);
+  const double d0 = x / nrm, d1 = y / nrm, d2 = z / nrm;
+  double b1x = 1, b1y = 1, b1z = -(d0 + d1) / d2;
+  const double n1 = sqrt(b1x * b1x + b1y * b1y + b1z * b1z);
+  b1x /= n1; b1y /= n1; b1z /= n1;
+  double b2x = b1y * d2 - b1z * d1, b2y = b1z * d0 - b1x * d2, b2z = b1x * d1 - b1y * d0;   // b1 x direction
+  const double n2 = sqrt(b2x * b2x + b2y * b2y + b2z * b2z);
+  b2x /= n2; b2y /= n2; b2z /= n2;
+  // A = range * hat(direction) * [b1 b2]
+  const double r = (double)range;
+  const double a1x = r * (d1 * b1z - d2 * b1y), a1y = r * (d2 * b1x - d0 * b1z), a1z = r * (d0 * b1y - d1 * b1x);
+  const double a2x = r * (d1 * b2z - d2 * b2y), a2y = r * (d2 * b2x - d0 * b2z), a2z = r * (d0 * b2y - d1 * b2x);
+  const double rv = (double)range_var;
+  const double d[3] = {d0, d1, d2}, a1[3] = {a1x, a1y, a1z}, a2[3] = {a2x, a2y, a2z};
+  double vb[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) vb[3 * i + j] = d[i] * rv * d[j] + (a1[i] * dv * a1[j] + a2[i] * dv * a2[j]);
+  // extrinsic: pnt = R p + t ; var = R var R^T
+  const double *R = ext;
+  pout[3 * (size_t)p] = R[0] * x + R[1] * y + R[2] * z + R[9];
+  pout[3 * (size_t)p + 1] = R[3] * x + R[4] * y + R[5] * z + R[10];
+  pout[3 * (size_t)p + 2] = R[6] * x + R[7] * y + R[8] * z + R[11];
+  double RV[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) RV[3 * i + j] = R[3 * i] * vb[j] + R[3 * i + 1] * vb[3 + j] + R[3 * i + 2] * vb[6 + j];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) var[9 * (size_t)p + 3 * i + j] = RV[3 * i] * R[3 * j] + RV[3 * i + 1] * R[3 * j + 1] + RV[3 * i + 2] * R[3 * j + 2];
+}
+
+// pvec_update (voxelslam.hpp:242-265) fused into the staging of a scan: var_world = R var R^T + phat rot_var phat^T + tsl_var
+// (pw = R p + t is recomputed by the insert kernels).  cov6 = [rot_var(9) | tsl_var(9)].
+__global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, const double *pts, const double *var, const double *pose, const double *cov6) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts;
+  const double bx = pts[(size_t)p * 3], by = pts[(size_t)p * 3 + 1], bz = pts[(size_t)p * 3 + 2];
+  m.px[((size_t)0 * W + slot) * mpz + p] = bx; m.px[((size_t)1 * W + slot) * mpz + p] = by; m.px[((size_t)2 * W + slot) * mpz + p] = bz;
+  const double *R = pose;
+  double v[9], RV[9], PR[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) v[k] = var[(size_t)p * 9 + k];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) RV[3 * r + c] = R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c] + R[3 * r + 2] * v[6 + c];
+  const double ph[9] = {0, -bz, by, bz, 0, -bx, -by, bx, 0};
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) PR[3 * r + c] = ph[3 * r] * cov6[c] + ph[3 * r + 1] * cov6[3 + c] + ph[3 * r + 2] * cov6[6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      m.pvar[((size_t)(3 * r + c) * W + slot) * mpz + p] = (RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1] + RV[3 * r + 2] * R[3 * c + 2]) +
+                                                           (PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1] + PR[3 * r + 2] * ph[3 * c + 2]) + cov6[9 + 3 * r + c];
+}
+
 // AoS host layout [n][3] / [n][9] -> the scan slot's SoA arrays
 __global__ void k_scan_to_soa(MapView m, int W, int slot, int n, const double *pts, const double *var) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -982,7 +1057,7 @@ inline int map_set_counter(MapStore &s, hipStream_t st, int which, int val, std:
 
 // cut_voxel / cut_voxel_multi for one scan
 inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, const double *pnt_body, const double *var, const double *pose,
-                         bool multi, std::string &err) {
+                         bool multi, std::string &err, const double *cov6 = nullptr) {
   const int W = s.opt.win_size;
   if (win_count < 0 || win_count >= W || n < 0 || !pose || (n > 0 && !pnt_body)) return VBA_ERR_BAD_ARG;
   int r = map_base(s, st, err);
@@ -1017,13 +1092,15 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
     else MAPCHK(hipEventSynchronize(s.pose_ev[k]));
     std::memcpy(s.h_pose_ring + 12 * k, pose, 12 * sizeof(double));
     MAPCHK(hipMemcpyAsync(s.v.poses, s.h_pose_ring + 12 * k, 12 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (cov6) MAPCHK(hipMemcpyAsync(s.v.poses + 16, cov6, 18 * sizeof(double), hipMemcpyHostToDevice, st));   // rot_var | tsl_var
     MAPCHK(hipEventRecord(s.pose_ev[k], st));
   }
   const MapParams P = map_params(s);
   const int nb = (n + 255) / 256;
   if (n < s.v.max_pts)   // stale assignments of the slot's previous occupant must not survive
     MAPCHK(hipMemsetAsync(s.v.pnode + (size_t)slot * s.v.max_pts + n, 0xFF, (size_t)(s.v.max_pts - n) * 4, st));
-  hipLaunchKernelGGL(k_scan_to_soa, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var);
+  if (cov6 && var) hipLaunchKernelGGL(k_scan_to_soa_pvec_update, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var, s.v.poses, s.v.poses + 16);
+  else hipLaunchKernelGGL(k_scan_to_soa, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var);
   r = map_set_counter(s, st, CNT_NEWSLOTS, 0, err); if (r) return r;
   r = map_set_counter(s, st, CNT_TOUCH, 0, err); if (r) return r;
   s.stamp++;
@@ -1033,7 +1110,7 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   MAPCHK(hipGetLastError());
   // no read-back: capacity was reserved for the worst case (n new roots), so this call cannot overflow
   s.ub_nodes += n; s.ub_roots += n; s.cnt_stale = true;
-  if (!is_device_ptr(pnt_body)) MAPCHK(hipStreamSynchronize(st));   // the caller's host buffers may go away
+  if (!is_device_ptr(pnt_body) || cov6) MAPCHK(hipStreamSynchronize(st));   // the caller's host buffers may go away
   return VBA_OK;
 }
 

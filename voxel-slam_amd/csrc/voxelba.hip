@@ -851,6 +851,33 @@ int vba_map_cut_voxel(vba_ctx *c, int win_count, int n, const double *pnt_body, 
   span_end(c, "insert", s);
   return st;
 }
+int vba_map_pvec_update_cut_voxel(vba_ctx *c, int win_count, int n, const double *pnt_body, const double *var_body, const double *pose,
+                                  const double *cov, int multi) {
+  if (!cov || !var_body) return VBA_ERR_BAD_ARG;
+  double cov6[18];
+  for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) { cov6[3 * r + k] = cov[r * VBA_DIM + k]; cov6[9 + 3 * r + k] = cov[(3 + r) * VBA_DIM + 3 + k]; }
+  TimedSpan s{};
+  span_begin(c, "insert", s);
+  const int st = map_cut_voxel(c->map, c->stream, win_count, n, pnt_body, var_body, pose, multi != 0, c->err, cov6);
+  span_end(c, "insert", s);
+  return st;
+}
+int vba_scan_var_init(vba_ctx *c, int n, const double *pnt_in, const double *ext_pose, double dept_err, double beam_err, double *pnt_out,
+                      double *var_out) {
+  if (n < 0 || (n > 0 && (!pnt_in || !pnt_out || !var_out)) || !ext_pose) return VBA_ERR_BAD_ARG;
+  if (n == 0) return VBA_OK;
+  int st = ensure_stage(c, ((size_t)n * 15 + 16) * sizeof(double));
+  if (st) return st;
+  double *d_in = (double *)c->d_stage, *d_out = d_in + (size_t)n * 3, *d_var = d_out + (size_t)n * 3, *d_ext = d_var + (size_t)n * 9;
+  HIPCHK(c, hipMemcpyAsync(d_in, pnt_in, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ext, ext_pose, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_var_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_in, d_out, d_var, d_ext, (float)dept_err, (float)beam_err);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(pnt_out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(var_out, d_var, (size_t)n * 9 * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VBA_OK;
+}
 int vba_map_cut_voxel_fix(vba_ctx *c, int n, const double *pnt_world, double jour) {
   return map_cut_voxel_fix(c->map, c->stream, n, pnt_world, jour, c->err);
 }
