@@ -106,6 +106,99 @@ def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16):
             "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
 
 
+def local_mapping_step(capi, torch, wl, scans, poses0, steps=12):
+    """One local-mapping step of SURVEY.md §8d = K5 marginalise the oldest scan + slide, K1 insert of the newest scan,
+    K2 recut/extract, 3 LM iterations (voxelslam.cpp:1922-1991, 2014-2019) on a steady-state window."""
+    import ctypes as C
+    from collections import deque
+    W = wl.win_size
+    ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+    dev = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in scans["points"]]
+
+    def insert_dev(slot, idx):
+        ctx._chk(ctx.lib.vba_map_cut_voxel(ctx.h, C.c_int(slot), C.c_int(dev[idx].shape[0]), C.c_void_p(dev[idx].data_ptr()), None,
+                                           poses0[idx].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(1)))
+
+    win = deque(range(W))
+    for i in range(W):
+        insert_dev(i, i)
+    ctx.recut(W, poses0, multi=True)
+    nxt = 0
+
+    def step(resident):
+        nonlocal nxt
+        pw = np.ascontiguousarray(poses0[list(win)])
+        ctx.margi(W, pw, jour=0.0)
+        ctx.slide(1)
+        win.popleft(); win.append(nxt)
+        if resident:
+            insert_dev(W - 1, nxt)
+        else:
+            ctx.cut_voxel(W - 1, scans["points"][nxt], poses0[nxt], multi=True)      # host scan: H2D inside the step
+        nxt = (nxt + 1) % W
+        pw = np.ascontiguousarray(poses0[list(win)])
+        ctx.recut(W, pw, multi=True)
+        ctx.lm_begin(pw, thd_num=2)
+        for _ in range(3):
+            ctx.lm_iterate(sync=False)
+        ctx.lm_end(fetch=True)                                                        # the node reads the poses back
+
+    out = {}
+    for name, resident in (("scan_resident_in_hbm", True), ("scan_from_host_memory", False)):
+        for _ in range(3):
+            step(resident)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(resident)
+        torch.cuda.synchronize()
+        out[name + "_ms"] = 1e3 * (time.perf_counter() - t0) / steps
+    out["steps"] = steps
+    out["planar_voxels"] = ctx.size()
+    out["what"] = "marginalise+slide, insert newest scan (%d pts), recut+extract, 3 LM iterations, poses fetched" % wl.n_pts
+    ctx.close()
+    return out
+
+
+def cold_residual_pass(ctx, torch, poses0, V, occ, W, reps=12):
+    """K4 with the caches flushed between repetitions (a 1 GiB scratch buffer is rewritten before every launch)."""
+    scratch = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    ctx.timing_enable(True); ctx.timing_select("residual"); ctx.timing_reset()
+    for k in range(reps):
+        scratch.fill_(float(k))
+        ctx.evaluate_only_residual(poses0)
+    t, n = ctx.timing_get("residual")
+    us = max(t / max(n, 1) - ctx.timing_null_spans(32), 1e-3)
+    ctx.timing_enable(False); ctx.timing_select(None)
+    by = V * ((occ + 1) * 80 + W * 8 + 8 + 176)
+    del scratch
+    return {"avg_launch_us": us, "launches": n, "achieved": by / (us * 1e-6) / 1e9, "unit": "GB/s",
+            "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "flush": "1 GiB device buffer rewritten before each launch"}
+
+
+def li_variant(ctx, capi, wl, scans, poses0, reps=15):
+    """LiDAR-inertial optimiser (LI_BA_Optimizer, voxel_map.hpp:504-714) on the same factor store: device K3/K4, IMU factors
+    and the 15W solve on the host."""
+    from voxel_slam_amd import synth
+    W = wl.win_size
+    imu_samples, vel, g = synth.make_imu(wl, gyr_sigma=1e-3, acc_sigma=1e-2)
+    nm = np.array([0.01] * 3 + [1.0] * 3); nw = np.array([1e-4] * 6)
+    imus = np.stack([capi.imu_preintegrate(t, gy, ac, np.zeros(3), np.zeros(3), nm, nw) for (t, gy, ac) in imu_samples])
+    states = np.zeros((W, 25))
+    for i in range(W):
+        states[i, 0] = 0.1 * i; states[i, 1:10] = poses0[i, :9]; states[i, 10:13] = poses0[i, 9:12]; states[i, 13:16] = vel[i]; states[i, 22:25] = g
+    ctx.evaluate_only_residual(poses0)
+    ctx.li_ba_damping_iter(states, imus, gravity=False, max_iter=3)
+    t0 = time.perf_counter(); n = 0
+    for _ in range(reps):
+        ctx.evaluate_only_residual(poses0)
+        out = ctx.li_ba_damping_iter(states, imus, gravity=False, max_iter=3)
+        n += len(out["trace"])
+    dt = time.perf_counter() - t0
+    return {"iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n, "iterations": n,
+            "what": "LI_BA_Optimizer::damping_iter, %d IMU factors, 150x150 system" % (W - 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +355,13 @@ def main():
     if world == 1 and not args.no_scaled:
         scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16)
 
+    cold = lms = liv = None
+    if world == 1 and not args.no_scaled:
+        cold = cold_residual_pass(ctx, torch, poses0, V_local, occ, W)
+        liv = li_variant(ctx, capi, wl, scans, poses0)
+        lms = local_mapping_step(capi, torch, wl, scans, poses0)
+    roof["cold"] = cold
+
     if rank == 0:
         out = {
             "metric": "local-BA iterations/sec (200k pts, W=10)", "value": args.steps / dt, "unit": "iterations/s",
@@ -273,6 +373,8 @@ def main():
                        "parallelism": "voxel-bucket shard x%d + all-reduce of [H|g|r]" % world if world > 1 else "single GPU"},
             "roofline": roof,
             "roofline_residual_pass_scene_x16": scaled,
+            "local_mapping_step": lms,
+            "li_ba_variant": liv,
             "full_window_rebuild": {"points": n_points, "wall_ms": 1e3 * t_rebuild, "insert_device_ms": 1e-3 * t_ins / max(n_rebuild, 1),
                                     "recut_extract_device_ms": 1e-3 * t_rec / max(n_rebuild, 1),
                                     "insert_algorithmic_GBps": n_points * 24 / (t_ins / max(n_rebuild, 1) * 1e-6) / 1e9 if t_ins > 0 else None},
