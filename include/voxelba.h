@@ -157,6 +157,19 @@ int vba_map_pvec_update_cut_voxel(vba_ctx *ctx, int win_count, int n, const doub
  * var_out [n][9] (host buffers; pnt_out may alias pnt_in). */
 int vba_scan_var_init(vba_ctx *ctx, int n, const double *pnt_in, const double *ext_pose, double dept_err, double beam_err,
                       double *pnt_out, double *var_out);
+/* down_sampling_voxel (tools.hpp:201-238): voxel-grid centroid filter.  pnt [n][3] (PCL float coordinates carried in
+ * doubles) -> pnt_out [<=n][3] centroids rounded to float, count_out = points per voxel (the `curvature` field after the
+ * call, TL:221/230), first_out = index of the voxel's first input point (whose intensity/normal fields the reference
+ * keeps); *n_out = number of voxels.  Output order = first occurrence (the reference's is unordered_map order).
+ * voxel_size < 0.001 returns the input unchanged (TL:203), counts 0.  Buffers may be HOST or DEVICE memory. */
+int vba_scan_down_sampling_voxel(vba_ctx *ctx, int n, const double *pnt, double voxel_size, double *pnt_out, int *count_out,
+                                 int *first_out, int *n_out);
+/* Undistortion inner loop of IMUEKF::motion_blur (ekf_imu.hpp:137-163).  pnt [n][3] in/out, curv [n] = per-point time
+ * offset (PointType::curvature), ascending as pcl_handler leaves them (VH:92-95); imu_poses [m][22] = the imu_poses
+ * vector (EK:87): t, R[9], p[3], v[3], angvel_avr[3], acc_imu[3]; end_pose [12] = xc.R, xc.p after propagation
+ * (EK:121-123); ext_pose [12] = Lid_rot_to_IMU, Lid_offset_to_IMU. */
+int vba_scan_undistort(vba_ctx *ctx, int n, double *pnt, const double *curv, int m, const double *imu_poses,
+                       const double *end_pose, const double *ext_pose);
 /* cut_voxel(feat_map, PVec&, wdsize, jour) for fixed (already-world) points (VM:2108-2152). */
 int vba_map_cut_voxel_fix(vba_ctx *ctx, int n, const double *pnt_world, double jour);
 /* multi_recut (VS:1682-1737) when multi != 0, or the loop "recut + tras_opt over surf_map" of motion_init

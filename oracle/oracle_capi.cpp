@@ -9,6 +9,7 @@
 //               dtime(1) dbg(3) dba(3) dbg_buf(3) dba_buf(3) cov(225)]       (304)  (IMU_PRE PI:15-28)
 #include "ba_oracle.hpp"
 #include "map_oracle.hpp"
+#include "scan_oracle.hpp"
 #include <chrono>
 
 using namespace vso;
@@ -287,6 +288,32 @@ void vso_pvec_update(int n, const double *pnt, double *var, const double *state,
   std::vector<V3> pw;
   pvec_update(pv, x, pw);
   for (int i = 0; i < n; i++) { m3_to(pv[i].var, var + 9 * i); v3_to(pw[i], pwld + 3 * i); }
+}
+
+// down_sampling_voxel (tools.hpp:201-238): pnt [n][3] -> out [<=n][3] (float values), count, first index; returns n_out
+int vso_down_sampling_voxel(int n, const double *pnt, double voxel_size, double *out, int *count, int *first) {
+  std::vector<V3> in(n);
+  for (int i = 0; i < n; i++) in[i] = v3_from(pnt + 3 * i);
+  std::vector<DsPoint> o;
+  down_sampling_voxel(in, voxel_size, o);
+  for (size_t i = 0; i < o.size(); i++) {
+    out[3 * i] = o[i].x; out[3 * i + 1] = o[i].y; out[3 * i + 2] = o[i].z;
+    count[i] = (int)o[i].curvature; first[i] = o[i].first;
+  }
+  return (int)o.size();
+}
+// motion_blur point loop (ekf_imu.hpp:137-163): pnt [n][3] in/out (float values), imu_poses [m][22] = t R p v angvel acc
+void vso_undistort(int n, double *pnt, const double *curv, int m, const double *imu_poses, const double *end_pose, const double *ext_pose) {
+  std::vector<float> pts(3 * (size_t)n), cv(n);
+  for (int i = 0; i < 3 * n; i++) pts[i] = (float)pnt[i];
+  for (int i = 0; i < n; i++) cv[i] = (float)curv[i];
+  std::vector<ImuPose> ip(m);
+  for (int j = 0; j < m; j++) {
+    const double *q = imu_poses + 22 * j;
+    ip[j].t = q[0]; ip[j].R = m3_from(q + 1); ip[j].p = v3_from(q + 10); ip[j].v = v3_from(q + 13); ip[j].angvel = v3_from(q + 16); ip[j].acc = v3_from(q + 19);
+  }
+  undistort(pts, cv, ip, m3_from(end_pose), v3_from(end_pose + 9), m3_from(ext_pose), v3_from(ext_pose + 9));
+  for (int i = 0; i < 3 * n; i++) pnt[i] = pts[i];
 }
 
 double vso_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

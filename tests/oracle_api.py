@@ -189,6 +189,21 @@ def pvec_update(pnt, var, state25, cov225):
     return var, pw
 
 
+def down_sampling_voxel(pnt, voxel_size):
+    pnt = _c(pnt); n = len(pnt)
+    out = np.empty((max(n, 1), 3)); cnt = np.zeros(max(n, 1), dtype=np.int32); first = np.zeros(max(n, 1), dtype=np.int32)
+    lib().vso_down_sampling_voxel.restype = C.c_int
+    m = lib().vso_down_sampling_voxel(C.c_int(n), _p(pnt), C.c_double(voxel_size), _p(out), cnt.ctypes.data_as(C.POINTER(C.c_int)),
+                                      first.ctypes.data_as(C.POINTER(C.c_int)))
+    return out[:m].copy(), cnt[:m].copy(), first[:m].copy()
+
+
+def undistort(pnt, curv, imu_poses22, end_pose12, ext_pose12):
+    pnt = _c(pnt).copy(); curv = _c(curv); ip = _c(imu_poses22)
+    lib().vso_undistort(C.c_int(len(pnt)), _p(pnt), _p(curv), C.c_int(len(ip)), _p(ip), _p(_c(end_pose12)), _p(_c(ext_pose12)))
+    return pnt
+
+
 def map_key(voxel_size, pw):
     pw = _c(pw); k = (C.c_longlong * 3)()
     lib().vso_map_key(C.c_double(voxel_size), _p(pw), k)

@@ -26,7 +26,7 @@ EXPORTS = [
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
-    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
+    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_undistort", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
@@ -268,6 +268,20 @@ class Context:
         po = np.empty_like(pnt); var = np.empty((len(pnt), 9))
         self._chk(self.lib.vba_scan_var_init(self.h, C.c_int(len(pnt)), _p(pnt), _p(ext), C.c_double(dept_err), C.c_double(beam_err), _p(po), _p(var)))
         return po, var
+
+    def down_sampling_voxel(self, pnt, voxel_size):
+        pnt = _c(pnt); n = len(pnt)
+        out = np.empty((max(n, 1), 3)); cnt = np.zeros(max(n, 1), dtype=np.int32); first = np.zeros(max(n, 1), dtype=np.int32)
+        m = C.c_int(0)
+        self._chk(self.lib.vba_scan_down_sampling_voxel(self.h, C.c_int(n), _p(pnt), C.c_double(voxel_size), _p(out),
+                                                        cnt.ctypes.data_as(C.POINTER(C.c_int)), first.ctypes.data_as(C.POINTER(C.c_int)), C.byref(m)))
+        return out[:m.value].copy(), cnt[:m.value].copy(), first[:m.value].copy()
+
+    def undistort(self, pnt, curv, imu_poses22, end_pose12, ext_pose12):
+        pnt = _c(pnt).copy(); curv = _c(curv); ip = _c(imu_poses22)
+        self._chk(self.lib.vba_scan_undistort(self.h, C.c_int(len(pnt)), _p(pnt), _p(curv), C.c_int(len(ip)), _p(ip), _p(_c(end_pose12)),
+                                              _p(_c(ext_pose12))))
+        return pnt
 
     def cut_voxel_fix(self, pnt_world, jour=0.0):
         pnt_world = _c(pnt_world)

@@ -7,6 +7,7 @@
 #include "vba_kernels_factor.hpp"
 #include "vba_kernels_map.hpp"
 #include "vba_kernels_lm.hpp"
+#include "vba_kernels_scan.hpp"
 #include <cstddef>
 #include "vba_hostmath.hpp"
 
@@ -876,6 +877,79 @@ int vba_scan_var_init(vba_ctx *c, int n, const double *pnt_in, const double *ext
   HIPCHK(c, hipMemcpyAsync(pnt_out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
   HIPCHK(c, hipMemcpyAsync(var_out, d_var, (size_t)n * 9 * sizeof(double), hipMemcpyDefault, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VBA_OK;
+}
+int vba_scan_down_sampling_voxel(vba_ctx *c, int n, const double *pnt, double voxel_size, double *pnt_out, int *count_out, int *first_out,
+                                 int *n_out) {
+  if (n < 0 || !n_out || (n > 0 && (!pnt || !pnt_out || !count_out || !first_out))) return VBA_ERR_BAD_ARG;
+  *n_out = 0;
+  if (n == 0) return VBA_OK;
+  if (voxel_size < 0.001) {                                             // TL:203
+    HIPCHK(c, hipMemcpyAsync(pnt_out, pnt, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+    std::vector<int> z(n, 0), id(n);
+    for (int i = 0; i < n; i++) id[i] = i;
+    HIPCHK(c, hipMemcpyAsync(count_out, z.data(), (size_t)n * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(first_out, id.data(), (size_t)n * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    return VBA_OK;
+  }
+  int cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  const int nb = (n + 255) / 256;
+  const size_t b_tab = (size_t)cap * sizeof(DsSlot), b_pnt = (size_t)n * 3 * sizeof(double), b_i = (((size_t)n * sizeof(int)) + 15) & ~(size_t)15,
+               b_blk = (((size_t)nb + 1) * sizeof(int) + 15) & ~(size_t)15;
+  int st = ensure_stage(c, b_tab + 2 * b_pnt + 3 * b_i + b_blk + 64);
+  if (st) return st;
+  char *base = (char *)c->d_stage;
+  DsSlot *tab = (DsSlot *)base;
+  double *d_in = (double *)(base + b_tab), *d_out = (double *)(base + b_tab + b_pnt);
+  int *d_slot = (int *)(base + b_tab + 2 * b_pnt), *d_cnt = (int *)((char *)d_slot + b_i), *d_first = (int *)((char *)d_cnt + b_i),
+      *d_blk = (int *)((char *)d_first + b_i), *d_n = d_blk + nb;
+  HIPCHK(c, hipMemcpyAsync(d_in, pnt, b_pnt, hipMemcpyDefault, c->stream));
+  TimedSpan sp{};
+  span_begin(c, "downsample", sp);
+  hipLaunchKernelGGL(k_ds_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, tab, cap);
+  hipLaunchKernelGGL(k_ds_insert, dim3(nb), dim3(256), 0, c->stream, n, d_in, voxel_size, tab, cap - 1, d_slot);
+  hipLaunchKernelGGL(k_ds_count, dim3(nb), dim3(256), 0, c->stream, n, tab, d_slot, d_blk);
+  hipLaunchKernelGGL(k_ds_scan, dim3(1), dim3(256), 0, c->stream, nb, d_blk, d_n);
+  hipLaunchKernelGGL(k_ds_emit, dim3(nb), dim3(256), 0, c->stream, n, tab, d_slot, d_blk, d_out, d_cnt, d_first);
+  span_end(c, "downsample", sp);
+  HIPCHK(c, hipGetLastError());
+  int m = 0;
+  HIPCHK(c, hipMemcpyAsync(&m, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(pnt_out, d_out, (size_t)m * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(count_out, d_cnt, (size_t)m * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(first_out, d_first, (size_t)m * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  *n_out = m;
+  return VBA_OK;
+}
+int vba_scan_undistort(vba_ctx *c, int n, double *pnt, const double *curv, int m, const double *imu_poses, const double *end_pose,
+                       const double *ext_pose) {
+  if (n < 0 || m < 0 || (n > 0 && (!pnt || !curv)) || (m > 0 && !imu_poses) || !end_pose || !ext_pose) return VBA_ERR_BAD_ARG;
+  if (n == 0 || m == 0) return VBA_OK;
+  const size_t nprm = (size_t)22 * m + 24;
+  int st = ensure_stage(c, ((size_t)n * 4 + nprm) * sizeof(double));
+  if (st) return st;
+  double *d_p = (double *)c->d_stage, *d_c = d_p + (size_t)n * 3, *d_prm = d_c + n;
+  std::vector<double> prm(nprm);
+  std::memcpy(prm.data(), imu_poses, (size_t)22 * m * sizeof(double));
+  std::memcpy(prm.data() + (size_t)22 * m, end_pose, 12 * sizeof(double));
+  std::memcpy(prm.data() + (size_t)22 * m + 12, ext_pose, 12 * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(d_p, pnt, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_c, curv, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_prm, prm.data(), nprm * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  TimedSpan sp{};
+  span_begin(c, "undistort", sp);
+  hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_p, d_c, m, d_prm);
+  span_end(c, "undistort", sp);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(pnt, d_p, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // prm is a host temporary
   return VBA_OK;
 }
 int vba_map_cut_voxel_fix(vba_ctx *c, int n, const double *pnt_world, double jour) {
