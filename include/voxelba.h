@@ -205,6 +205,32 @@ int vba_odom_lio_state_estimation(vba_ctx *ctx, int n, const double *pnt_body, c
                                   double *cov, int *ok);
 
 /* ------------------------------------------------------------------------------------------------
+ * Hierarchical global BA ("next #3"), one keyframe window per call; wdsize must equal the context's
+ * win_size (windows of 10 keyframes, VS:3033; larger top-level windows are not supported yet).
+ * Keyframe clouds are passed ragged: pnt_local [offsets[wdsize]][3] holds keyframe i's points (its own frame, PCL float
+ * values in doubles) in rows offsets[i]..offsets[i+1]; HOST or DEVICE memory.  gba_eigen_value_array is ALREADY INVERTED
+ * (VS:3022-3024).
+ *
+ * vba_gba_build = OctreeGBA::cut_voxel for every keyframe (LR:439-479) + OctreeGBA_multi_recut (LR:483-537): fills the
+ * context's factor store (what `LidarFactor voxhess(wdsize)` holds at VS:2889-2890).
+ *
+ * vba_hba_add_edge = VOXEL_SLAM::HBA_add_edge (VS:2822-3015) on an already filtered keyframe set: up to max_iter
+ * rounds of {octree rebuild, Lidar_BA_Optimizer::damping_iter(xs, voxhess, &hess, resis, 4)} with the convergence
+ * ladder of VS:2871-2915 (the last round uses the context's voxel_size / plane_eigen_value_thre / min_eigen_value),
+ * poses [wdsize][12] in/out, then one edge per keyframe pair whose six diagonal Hessian entries are all >= 1e-6
+ * (VS:2926-2951): edges_out rows = i, j, rot[9] = R_i^T R_j, tra[3] = R_i^T (p_j - p_i), v6[6] = 1/|H| — the arguments
+ * of PGO_Edges::push (LR:247).  cloud_out (optional, capacity offsets[wdsize] rows) receives the submap cloud of
+ * VS:2954-2989 (all points in keyframe 0's frame, down_sampling_voxel(voxel_size / 8)), cloud_count its per-voxel
+ * counts.  resis_log (optional, [max_iter][2]) receives resis[0], resis[1] of every round.
+ * Returns VBA_ERR_TOO_FEW_VOXELS where the reference prints "Too Less Voxel" and exits. */
+int vba_gba_build(vba_ctx *ctx, int wdsize, const int *offsets, const double *pnt_local, const double *poses,
+                  double gba_voxel_size, double gba_min_eigen_value, const double *gba_eigen_value_array);
+int vba_hba_add_edge(vba_ctx *ctx, int wdsize, const int *offsets, const double *pnt_local, double *poses,
+                     double gba_voxel_size, double gba_min_eigen_value, const double *gba_eigen_value_array, int max_iter,
+                     int thread_num, double *edges_out, int *n_edges, double *cloud_out, int *cloud_count, int *n_cloud,
+                     double *resis_log, int *n_log);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU: voxels are sharded by root-voxel hash bucket; each rank evaluates its
  * shard and the packed [H | g | r] buffer is summed across ranks (the thread-sum of VM:571-581).
  * The reduction itself is supplied by the host program (torch.distributed/RCCL all_reduce on the

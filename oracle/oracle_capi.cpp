@@ -10,6 +10,7 @@
 #include "ba_oracle.hpp"
 #include "map_oracle.hpp"
 #include "scan_oracle.hpp"
+#include "gba_oracle.hpp"
 #include <chrono>
 
 using namespace vso;
@@ -314,6 +315,55 @@ void vso_undistort(int n, double *pnt, const double *curv, int m, const double *
   }
   undistort(pts, cv, ip, m3_from(end_pose), v3_from(end_pose + 9), m3_from(ext_pose), v3_from(ext_pose + 9));
   for (int i = 0; i < 3 * n; i++) pnt[i] = pts[i];
+}
+
+// ---- hierarchical global BA (gba_oracle.hpp).  cfg13 = gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array[4],
+// voxel_size, min_eigen_value, plane_eigen_value_thre[4], max_layer
+static GbaCfg gba_cfg_from(const double *c) {
+  GbaCfg g;
+  g.gba_voxel_size = c[0]; g.gba_min_eigen_value = c[1];
+  for (int k = 0; k < 4; k++) { g.gba_eigen_value_array[k] = c[2 + k]; g.plane_eigen_value_thre[k] = c[8 + k]; }
+  g.voxel_size = c[6]; g.min_eigen_value = c[7]; g.max_layer = (int)c[12];
+  return g;
+}
+static std::vector<std::vector<V3>> clouds_from(int wdsize, const int *offsets, const double *pnt) {
+  std::vector<std::vector<V3>> cl(wdsize);
+  for (int i = 0; i < wdsize; i++)
+    for (int k = offsets[i]; k < offsets[i + 1]; k++) cl[i].push_back(v3_from(pnt + 3 * (size_t)k));
+  return cl;
+}
+void vso_gba_build(void *fh, int wdsize, const int *offsets, const double *pnt, const double *poses, const double *cfg13) {
+  GbaMap map; map.cfg = gba_cfg_from(cfg13);
+  std::vector<IMUST> xs = poses_to_states(poses, wdsize);
+  auto cl = clouds_from(wdsize, offsets, pnt);
+  for (int i = 0; i < wdsize; i++) map.cut_voxel(xs[i], cl[i], i, wdsize);
+  LidarFactor *f = (LidarFactor *)fh;
+  f->clear();
+  map.multi_recut(*f);
+}
+// edges_out rows: i, j, rot[9], tra[3], v6[6] (20 doubles)
+int vso_hba_add_edge(int wdsize, const int *offsets, const double *pnt, double *poses, const double *cfg13, int max_iter, int thread_num,
+                     double *edges_out, int *n_edges, double *cloud_out, int *cloud_cnt, int *n_cloud, double *resis_log, int *n_log) {
+  std::vector<IMUST> xs = poses_to_states(poses, wdsize);
+  auto cl = clouds_from(wdsize, offsets, pnt);
+  std::vector<GbaEdge> edges;
+  std::vector<DsPoint> cloud;
+  std::vector<double> rl;
+  int st = hba_add_edge(xs, cl, gba_cfg_from(cfg13), max_iter, thread_num, edges, cloud_out ? &cloud : nullptr, &rl);
+  if (st) return st;
+  states_to_poses(xs, poses);
+  for (size_t e = 0; e < edges.size(); e++) {
+    double *o = edges_out + 20 * e;
+    o[0] = edges[e].i; o[1] = edges[e].j; m3_to(edges[e].rot, o + 2); v3_to(edges[e].tra, o + 11);
+    for (int k = 0; k < 6; k++) o[14 + k] = edges[e].v6[k];
+  }
+  *n_edges = (int)edges.size();
+  if (cloud_out) {
+    for (size_t i = 0; i < cloud.size(); i++) { cloud_out[3 * i] = cloud[i].x; cloud_out[3 * i + 1] = cloud[i].y; cloud_out[3 * i + 2] = cloud[i].z; cloud_cnt[i] = (int)cloud[i].curvature; }
+    *n_cloud = (int)cloud.size();
+  }
+  if (resis_log) { for (size_t i = 0; i < rl.size(); i++) resis_log[i] = rl[i]; *n_log = (int)rl.size(); }
+  return 0;
 }
 
 double vso_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -204,6 +204,41 @@ def undistort(pnt, curv, imu_poses22, end_pose12, ext_pose12):
     return pnt
 
 
+def gba_cfg13(gba_voxel_size, gba_min_eigen_value, gba_eig, voxel_size, min_eigen_value, plane_eig, max_layer):
+    return np.array([gba_voxel_size, gba_min_eigen_value, *gba_eig, voxel_size, min_eigen_value, *plane_eig, max_layer], dtype=np.float64)
+
+
+def _ragged(clouds):
+    off = np.zeros(len(clouds) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(c) for c in clouds])
+    return off, _c(np.concatenate(clouds))
+
+
+def gba_build(clouds, poses, cfg13):
+    """OctreeGBA::cut_voxel over all keyframes + OctreeGBA_multi_recut (loop_refine.hpp:439-537) -> Factor."""
+    W = len(clouds)
+    off, pnt = _ragged(clouds)
+    f = Factor(W)
+    lib().vso_gba_build(f.h, C.c_int(W), off.ctypes.data_as(C.POINTER(C.c_int)), _p(pnt), _p(_c(poses)), _p(_c(cfg13)))
+    return f
+
+
+def hba_add_edge(clouds, poses, cfg13, max_iter, thread_num, want_cloud=True):
+    """HBA_add_edge (voxelslam.cpp:2822-3015)."""
+    W = len(clouds)
+    off, pnt = _ragged(clouds)
+    poses = _c(poses).copy()
+    edges = np.zeros((W * (W - 1) // 2 + 1, 20)); ne = C.c_int(0)
+    cloud = np.zeros((len(pnt), 3)); ccnt = np.zeros(len(pnt), dtype=np.int32); nc = C.c_int(0)
+    rl = np.zeros(2 * max_iter + 2); nl = C.c_int(0)
+    lib().vso_hba_add_edge.restype = C.c_int
+    st = lib().vso_hba_add_edge(C.c_int(W), off.ctypes.data_as(C.POINTER(C.c_int)), _p(pnt), _p(poses), _p(_c(cfg13)), C.c_int(max_iter),
+                                C.c_int(thread_num), _p(edges), C.byref(ne), _p(cloud) if want_cloud else None,
+                                ccnt.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nc), _p(rl), C.byref(nl))
+    return dict(status=st, poses=poses, edges=edges[:ne.value].copy(), cloud=cloud[:nc.value].copy(), cloud_count=ccnt[:nc.value].copy(),
+                resis=rl[:nl.value].reshape(-1, 2).copy())
+
+
 def map_key(voxel_size, pw):
     pw = _c(pw); k = (C.c_longlong * 3)()
     lib().vso_map_key(C.c_double(voxel_size), _p(pw), k)

@@ -26,7 +26,7 @@ EXPORTS = [
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
-    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_undistort", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
+    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_undistort", "vba_gba_build", "vba_hba_add_edge", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
@@ -326,6 +326,33 @@ class Context:
         return bool(ok.value), state, cov
 
     # ---- multi-GPU / timing
+    # ---- hierarchical global BA
+    @staticmethod
+    def _ragged(clouds):
+        off = np.zeros(len(clouds) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(c) for c in clouds])
+        return off, _c(np.concatenate(clouds))
+
+    def gba_build(self, clouds, poses, gba_voxel_size, gba_min_eigen_value, gba_eig):
+        off, pnt = self._ragged(clouds)
+        self._chk(self.lib.vba_gba_build(self.h, C.c_int(len(clouds)), off.ctypes.data_as(C.POINTER(C.c_int)), _p(pnt), _p(_c(poses)),
+                                         C.c_double(gba_voxel_size), C.c_double(gba_min_eigen_value), _p(_c(gba_eig))))
+        return self.size()
+
+    def hba_add_edge(self, clouds, poses, gba_voxel_size, gba_min_eigen_value, gba_eig, max_iter, thread_num, want_cloud=True):
+        W = len(clouds)
+        off, pnt = self._ragged(clouds)
+        poses = _c(poses).copy()
+        edges = np.zeros((W * (W - 1) // 2 + 1, 20)); ne = C.c_int(0)
+        cloud = np.zeros((max(len(pnt), 1), 3)); ccnt = np.zeros(max(len(pnt), 1), dtype=np.int32); nc = C.c_int(0)
+        rl = np.zeros((max_iter + 1, 2)); nl = C.c_int(0)
+        self._chk(self.lib.vba_hba_add_edge(self.h, C.c_int(W), off.ctypes.data_as(C.POINTER(C.c_int)), _p(pnt), _p(poses),
+                                            C.c_double(gba_voxel_size), C.c_double(gba_min_eigen_value), _p(_c(gba_eig)), C.c_int(max_iter),
+                                            C.c_int(thread_num), _p(edges), C.byref(ne), _p(cloud) if want_cloud else None,
+                                            ccnt.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nc), _p(rl), C.byref(nl)))
+        return dict(poses=poses, edges=edges[:ne.value].copy(), cloud=cloud[:nc.value].copy(), cloud_count=ccnt[:nc.value].copy(),
+                    resis=rl[:nl.value].copy())
+
     def set_shard(self, rank, n_ranks):
         self._chk(self.lib.vba_set_shard(self.h, C.c_int(rank), C.c_int(n_ranks)))
 

@@ -8,6 +8,7 @@
 #include "vba_kernels_map.hpp"
 #include "vba_kernels_lm.hpp"
 #include "vba_kernels_scan.hpp"
+#include "vba_kernels_gba.hpp"
 #include <cstddef>
 #include "vba_hostmath.hpp"
 
@@ -79,6 +80,9 @@ struct vba_ctx {
   std::vector<double> trace;
 
   MapStore map;
+  GbaStore gba;
+  double *d_refpts = nullptr;     // submap cloud staging (HBA_add_edge)
+  size_t refpts_doubles = 0;
 
   void set_error(const std::string &s) { err = s; }
 };
@@ -412,6 +416,8 @@ void vba_destroy(vba_ctx *c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   map_free(c->map);
+  c->gba.free_all();
+  if (c->d_refpts) hipFree(c->d_refpts);
   double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out, c->d_full, c->d_scal};
   for (double *q : p) if (q) hipFree(q);
   if (c->d_stage) hipFree(c->d_stage);
@@ -779,6 +785,126 @@ int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity
   std::memcpy(states, x.data(), (size_t)W * 25 * sizeof(double));
   if (hess) std::memcpy(hess, saved.data(), saved.size() * sizeof(double));
   if (gravity && resis2) { resis2[0] = resis_first; resis2[1] = residual2; }
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- hierarchical global BA (vba_kernels_gba.hpp)
+static GbaParams gba_params(vba_ctx *c, double voxel_size, double min_eig, const double *eig_array) {
+  GbaParams P;
+  P.voxel_size = voxel_size; P.min_eigen_value = min_eig; P.max_layer = c->opt.max_layer;
+  for (int k = 0; k < 4; k++) P.eig_array[k] = eig_array[k];
+  return P;
+}
+static int gba_build_into_store(vba_ctx *c, int wdsize, const int *offsets, const double *pl, const double *poses, const GbaParams &P) {
+  int nf = 0;
+  TimedSpan sp{};
+  span_begin(c, "gba_build", sp);
+  int st = gba_build(c->gba, c->stream, wdsize, offsets, pl, poses, P, &nf, c->err);
+  if (st) return st;
+  c->nvox = 0;
+  st = factor_reserve(c, nf > 0 ? nf : 1);
+  if (st) return st;
+  if (nf > 0) {
+    const int nn = c->gba.h_cnt[GCNT_NODES] < c->gba.v.cap ? c->gba.h_cnt[GCNT_NODES] : c->gba.v.cap;
+    hipLaunchKernelGGL(k_gba_extract, dim3((nn + 255) / 256), dim3(256), 0, c->stream, c->gba.v, c->fv);
+    HIPCHK(c, hipGetLastError());
+  }
+  span_end(c, "gba_build", sp);
+  c->nvox = nf;
+  return VBA_OK;
+}
+static int gba_check(vba_ctx *c, int wdsize, const int *offsets, const double *pl, const double *poses) {
+  if (wdsize != c->opt.win_size) return VBA_ERR_UNSUPPORTED_WINDOW;
+  if (!offsets || !poses || offsets[0] != 0) return VBA_ERR_BAD_ARG;
+  for (int i = 0; i < wdsize; i++) if (offsets[i + 1] < offsets[i]) return VBA_ERR_BAD_ARG;
+  if (offsets[wdsize] > 0 && !pl) return VBA_ERR_BAD_ARG;
+  return VBA_OK;
+}
+int vba_gba_build(vba_ctx *c, int wdsize, const int *offsets, const double *pnt_local, const double *poses, double gba_voxel_size,
+                  double gba_min_eigen_value, const double *gba_eigen_value_array) {
+  int st = gba_check(c, wdsize, offsets, pnt_local, poses);
+  if (st) return st;
+  if (!gba_eigen_value_array) return VBA_ERR_BAD_ARG;
+  return gba_build_into_store(c, wdsize, offsets, pnt_local, poses, gba_params(c, gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array));
+}
+
+int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *pnt_local, double *poses, double gba_voxel_size,
+                     double gba_min_eigen_value, const double *gba_eigen_value_array, int max_iter, int thread_num, double *edges_out, int *n_edges,
+                     double *cloud_out, int *cloud_count, int *n_cloud, double *resis_log, int *n_log) {
+  int st = gba_check(c, wdsize, offsets, pnt_local, poses);
+  if (st) return st;
+  if (!gba_eigen_value_array || !edges_out || !n_edges || (cloud_out && (!cloud_count || !n_cloud))) return VBA_ERR_BAD_ARG;
+  const int W = wdsize, n6 = 6 * W, n = offsets[W];
+  *n_edges = 0;
+  if (n_log) *n_log = 0;
+  // the keyframe clouds stay in HBM for the whole call (every outer iteration re-cuts them with the current poses)
+  if ((size_t)n * 3 > c->refpts_doubles) {
+    if (c->d_refpts) hipFree(c->d_refpts);
+    c->refpts_doubles = (size_t)n * 3 + 3072;
+    HIPCHK(c, hipMalloc((void **)&c->d_refpts, 2 * c->refpts_doubles * sizeof(double)));
+  }
+  double *d_pl = c->d_refpts, *d_ref = c->d_refpts + c->refpts_doubles;
+  if (n > 0) HIPCHK(c, hipMemcpyAsync(d_pl, pnt_local, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  GbaParams P = gba_params(c, gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array);
+  std::vector<double> hess((size_t)n6 * n6, 0.0);
+  const int up = 4;                                                       // VS:2866
+  int converge_flag = 0;
+  double converge_thre = 0.05;
+  for (int iterCnt = 0; iterCnt < max_iter; iterCnt++) {
+    if (converge_flag == 1 || iterCnt == max_iter - 1)                    // VS:2871-2881: last pass with the local-map parameters
+      P = gba_params(c, c->opt.voxel_size, c->opt.min_eigen_value, c->opt.plane_eigen_value_thre);
+    st = gba_build_into_store(c, W, offsets, d_pl, poses, P);
+    if (st) return st;
+    double resis[2] = {0, 0};
+    int is_converge = 0;
+    st = vba_lidar_ba_damping_iter(c, poses, hess.data(), resis, up, thread_num, &is_converge);
+    if (st) return st;
+    if (resis_log && n_log) { resis_log[2 * *n_log] = resis[0]; resis_log[2 * *n_log + 1] = resis[1]; (*n_log)++; }
+    if ((std::fabs(resis[0] - resis[1]) / resis[0] < converge_thre && is_converge) || (iterCnt == max_iter - 2 && converge_flag == 0)) {
+      converge_thre = 0.01;                                               // VS:2903-2915
+      if (converge_flag == 0) converge_flag = 1;
+      else if (converge_flag == 1) break;
+    }
+  }
+  int ne = 0;
+  for (int i = 0; i < W - 1; i++)
+    for (int j = i + 1; j < W; j++) {                                     // VS:2926-2951
+      bool isAdd = true;
+      double v6[6];
+      for (int k = 0; k < 6; k++) {
+        const double hc = std::fabs(hess[(size_t)(6 * i + k) * n6 + 6 * j + k]);
+        if (hc < 1e-6) { isAdd = false; break; }
+        v6[k] = 1.0 / hc;
+      }
+      if (!isAdd) continue;
+      double *o = edges_out + 20 * (size_t)ne++;
+      const double *Ri = poses + 12 * i, *Rj = poses + 12 * j;
+      o[0] = i; o[1] = j;
+      vbh::m3_Tmul(Ri, Rj, o + 2);
+      const double d[3] = {Rj[9] - Ri[9], Rj[10] - Ri[10], Rj[11] - Ri[11]};
+      vbh::m3_Tvec(Ri, d, o + 11);
+      for (int k = 0; k < 6; k++) o[14 + k] = v6[k];
+    }
+  *n_edges = ne;
+  if (cloud_out) {                                                        // VS:2954-2989
+    *n_cloud = 0;
+    if (n > 0) {
+      std::vector<double> rel((size_t)W * 12);
+      for (int i = 0; i < W; i++) {
+        const double *R0 = poses, *Ri = poses + 12 * i;
+        vbh::m3_Tmul(R0, Ri, rel.data() + 12 * i);
+        const double d[3] = {Ri[9] - R0[9], Ri[10] - R0[10], Ri[11] - R0[11]};
+        vbh::m3_Tvec(R0, d, rel.data() + 12 * i + 9);
+      }
+      HIPCHK(c, hipMemcpyAsync(c->gba.v.poses, rel.data(), rel.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_gba_to_ref, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, W, c->gba.v.offsets, d_pl, c->gba.v.poses, d_ref);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));      // rel is a host temporary
+      std::vector<int> first(n);
+      st = vba_scan_down_sampling_voxel(c, n, d_ref, c->opt.voxel_size / 8, cloud_out, cloud_count, first.data(), n_cloud);
+      if (st) return st;
+    }
+  }
   return VBA_OK;
 }
 
