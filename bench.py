@@ -199,6 +199,40 @@ def li_variant(ctx, capi, wl, scans, poses0, reps=15):
             "what": "LI_BA_Optimizer::damping_iter, %d IMU factors, 150x150 system" % (W - 1)}
 
 
+def hba_window(capi, torch, reps=10, cpu=True):
+    """One bottom-layer window of the hierarchical global BA (BASELINE cfg5 shape: 10 keyframes x 50k points, stride-5
+    windows are independent): HBA_add_edge(xs, smp_local, gba_edges1, mps, 1, 2, plptr) as thd_globalmapping calls it
+    (voxelslam.cpp:3086) = octree build + 4 LM iterations + edges + down-sampled submap cloud."""
+    import dataclasses
+    from voxel_slam_amd import synth
+    wl = dataclasses.replace(synth.CONFIGS["hesai200k_w10"], name="hba50k_w10", n_pts=50000)
+    s = synth.make_scans(wl)
+    clouds = [p.astype(np.float32).astype(np.float64) for p in s["points"]]
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    gba = (2.0, 0.1, [0.25] * 4)                       # config/avia.yaml:59-65, ratios inverted
+    ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+    out = ctx.hba_add_edge(clouds, poses, *gba, 1, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = ctx.hba_add_edge(clouds, poses, *gba, 1, 2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    res = {"workload": "10 keyframes x %d pts, GBA voxel 2 m, max_iter 1, thread_num 2" % wl.n_pts, "window_ms": 1e3 * dt, "windows_per_s": 1.0 / dt,
+           "planar_voxels": ctx.size(), "edges": int(len(out["edges"])), "submap_cloud_points": int(len(out["cloud"])),
+           "what": "host clouds uploaded per call; octree build, 4 LM iterations, edges, submap cloud fetched"}
+    ctx.close()
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        o = capi.options_from_workload(wl)
+        cfg = oracle_api.gba_cfg13(gba[0], gba[1], gba[2], o.voxel_size, o.min_eigen_value, list(o.plane_eigen_value_thre), o.max_layer)
+        t0 = time.perf_counter()
+        oracle_api.hba_add_edge(clouds, poses, cfg, 1, 2)
+        res["cpu_port_window_ms"] = 1e3 * (time.perf_counter() - t0)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,11 +389,12 @@ def main():
     if world == 1 and not args.no_scaled:
         scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16)
 
-    cold = lms = liv = None
+    cold = lms = liv = hba = None
     if world == 1 and not args.no_scaled:
         cold = cold_residual_pass(ctx, torch, poses0, V_local, occ, W)
         liv = li_variant(ctx, capi, wl, scans, poses0)
         lms = local_mapping_step(capi, torch, wl, scans, poses0)
+        hba = hba_window(capi, torch, cpu=not args.no_cpu_baseline)
     roof["cold"] = cold
 
     if rank == 0:
@@ -375,6 +410,7 @@ def main():
             "roofline_residual_pass_scene_x16": scaled,
             "local_mapping_step": lms,
             "li_ba_variant": liv,
+            "hba_window": hba,
             "full_window_rebuild": {"points": n_points, "wall_ms": 1e3 * t_rebuild, "insert_device_ms": 1e-3 * t_ins / max(n_rebuild, 1),
                                     "recut_extract_device_ms": 1e-3 * t_rec / max(n_rebuild, 1),
                                     "insert_algorithmic_GBps": n_points * 24 / (t_ins / max(n_rebuild, 1) * 1e-6) / 1e9 if t_ins > 0 else None},
