@@ -165,7 +165,7 @@ def test_too_few_voxels_status(capi):
 
 
 def _li_problem(synth, capi, wl_name):
-    wl = synth.CONFIGS[wl_name]
+    wl = _workload(synth, wl_name)
     s = synth.make_scans(wl)
     fac = synth.root_factors(s["points"], s["R0"], s["p0"], wl)
     W = wl.win_size
@@ -179,9 +179,11 @@ def _li_problem(synth, capi, wl_name):
     return wl, fac, states, imus
 
 
+@pytest.mark.parametrize("name", ["room20k_w4", "spin40k_w10"])
 @pytest.mark.parametrize("gravity", [False, True])
-def test_li_ba_damping_iter_parity(capi, oracle, synth, gravity):
-    wl, fac, states, imus = _li_problem(synth, capi, "room20k_w4")
+def test_li_ba_damping_iter_parity(capi, oracle, synth, gravity, name):
+    # (W <= 10 runs fully on the device: IMU factors, the 15W(+3) solve and the accept/reject bookkeeping)
+    wl, fac, states, imus = _li_problem(synth, capi, name)
     W = wl.win_size
     ctx = _ctx(capi, W, imu_coef=wl.imu_coef); ctx.push_dict(fac)
     f = oracle.Factor(W); f.push_dict(fac)

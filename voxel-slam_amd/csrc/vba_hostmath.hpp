@@ -8,40 +8,46 @@
 #include <vector>
 #include <algorithm>
 
+#if defined(__HIPCC__)
+#define VBH_HD __host__ __device__
+#else
+#define VBH_HD
+#endif
+
 namespace vbh {
 
 // ---- 3-vectors / 3x3 (row-major)
-inline void m3_identity(double *M) { std::memset(M, 0, 9 * sizeof(double)); M[0] = M[4] = M[8] = 1.0; }
-inline void m3_mul(const double *A, const double *B, double *C) {  // C = A B (C may not alias)
+VBH_HD inline void m3_identity(double *M) { for (int i = 0; i < 9; i++) M[i] = 0.0; M[0] = M[4] = M[8] = 1.0; }
+VBH_HD inline void m3_mul(const double *A, const double *B, double *C) {  // C = A B (C may not alias)
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
 }
-inline void m3_mulT(const double *A, const double *B, double *C) {  // C = A B^T
+VBH_HD inline void m3_mulT(const double *A, const double *B, double *C) {  // C = A B^T
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) C[3 * r + c] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
 }
-inline void m3_Tmul(const double *A, const double *B, double *C) {  // C = A^T B
+VBH_HD inline void m3_Tmul(const double *A, const double *B, double *C) {  // C = A^T B
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) C[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
 }
-inline void m3_vec(const double *A, const double *x, double *y) {
+VBH_HD inline void m3_vec(const double *A, const double *x, double *y) {
   for (int r = 0; r < 3; r++) y[r] = A[3 * r] * x[0] + A[3 * r + 1] * x[1] + A[3 * r + 2] * x[2];
 }
-inline void m3_Tvec(const double *A, const double *x, double *y) {
+VBH_HD inline void m3_Tvec(const double *A, const double *x, double *y) {
   for (int r = 0; r < 3; r++) y[r] = A[r] * x[0] + A[3 + r] * x[1] + A[6 + r] * x[2];
 }
-inline void m3_transpose(const double *A, double *T) {
+VBH_HD inline void m3_transpose(const double *A, double *T) {
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) T[3 * c + r] = A[3 * r + c];
 }
-inline void hat(const double *v, double *M) {  // TL:93-100
+VBH_HD inline void hat(const double *v, double *M) {  // TL:93-100
   M[0] = 0; M[1] = -v[2]; M[2] = v[1];
   M[3] = v[2]; M[4] = 0; M[5] = -v[0];
   M[6] = -v[1]; M[7] = v[0]; M[8] = 0;
 }
-inline double norm3(const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+VBH_HD inline double norm3(const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 // Rodrigues about unit axis ax with angle th: I + sin K + (1-cos) K^2
-inline void rodrigues(const double *ax, double th, double *R) {
+VBH_HD inline void rodrigues(const double *ax, double th, double *R) {
   double K[9], K2[9];
   hat(ax, K);
   m3_mul(K, K, K2);
@@ -49,24 +55,24 @@ inline void rodrigues(const double *ax, double th, double *R) {
   for (int i = 0; i < 9; i++) R[i] = s * K[i] + c1 * K2[i];
   R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
 }
-inline void so3_exp(const double *w, double *R) {  // TL:51-66 (threshold 1e-11)
+VBH_HD inline void so3_exp(const double *w, double *R) {  // TL:51-66 (threshold 1e-11)
   const double n = norm3(w);
   if (n >= 1e-11) { const double ax[3] = {w[0] / n, w[1] / n, w[2] / n}; rodrigues(ax, n, R); }
   else m3_identity(R);
 }
-inline void so3_exp_dt(const double *w, double dt, double *R) {  // TL:68-84 (threshold 1e-7)
+VBH_HD inline void so3_exp_dt(const double *w, double dt, double *R) {  // TL:68-84 (threshold 1e-7)
   const double n = norm3(w);
   if (n > 1e-7) { const double ax[3] = {w[0] / n, w[1] / n, w[2] / n}; rodrigues(ax, n * dt, R); }
   else m3_identity(R);
 }
-inline void so3_log(const double *R, double *w) {  // TL:86-91
+VBH_HD inline void so3_log(const double *R, double *w) {  // TL:86-91
   const double tr = R[0] + R[4] + R[8];
   const double theta = (tr > 3.0 - 1e-6) ? 0.0 : std::acos(0.5 * (tr - 1));
   const double K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
   const double f = (std::fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / std::sin(theta));
   for (int i = 0; i < 3; i++) w[i] = f * K[i];
 }
-inline void so3_jr(const double *vec, double *J) {  // TL:102-116
+VBH_HD inline void so3_jr(const double *vec, double *J) {  // TL:102-116
   const double ang = norm3(vec);
   if (ang < 1e-9) { m3_identity(J); return; }
   const double a[3] = {vec[0] / ang, vec[1] / ang, vec[2] / ang};
@@ -77,7 +83,7 @@ inline void so3_jr(const double *vec, double *J) {  // TL:102-116
     for (int c = 0; c < 3; c++) J[3 * r + c] = (r == c ? ra : 0.0) + (1 - ra) * a[r] * a[c] - k * H[3 * r + c];
 }
 // Eigen::AngleAxisd(Matrix3d) = matrix -> quaternion -> angle/axis (used at TL:120-122)
-inline void angle_axis(const double *m, double &angle, double *axis) {
+VBH_HD inline void angle_axis(const double *m, double &angle, double *axis) {
   double q[4];  // w x y z
   double t = m[0] + m[4] + m[8];
   if (t > 0) {
@@ -104,7 +110,7 @@ inline void angle_axis(const double *m, double &angle, double *axis) {
     axis[0] = q[1] / n; axis[1] = q[2] / n; axis[2] = q[3] / n;
   } else { angle = 0; axis[0] = 1; axis[1] = 0; axis[2] = 0; }
 }
-inline void so3_jr_inv(const double *R, double *J) {  // TL:118-133
+VBH_HD inline void so3_jr_inv(const double *R, double *J) {  // TL:118-133
   double ang, a[3];
   angle_axis(R, ang, a);
   if (ang < 1e-9) { m3_identity(J); return; }
@@ -132,7 +138,7 @@ inline void mat_mul_ABt(const double *A, const double *B, double *C, int n, int 
       C[r * m + c] = s;
     }
 }
-inline void set_block3(double *M, int ld, int r0, int c0, const double *B, double scale = 1.0) {
+VBH_HD inline void set_block3(double *M, int ld, int r0, int c0, const double *B, double scale = 1.0) {
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[(r0 + r) * ld + c0 + c] = scale * B[3 * r + c];
 }
 
@@ -295,8 +301,9 @@ inline void imu_push(ImuPre &m, int n, const double *t, const double *gyr, const
   }
 }
 
-// PI:137-212 / PI:214-294.  jtj (nb x nb), gg (nb), nb = 30 (+3 with gravity).  Returns r^T cov^-1 r.
-inline double imu_evaluate(const ImuPre &m, const State &s1, const State &s2, bool with_g, bool jac, double *jtj, double *gg) {
+// PI:137-212 / PI:214-294, the part that does not involve cov: residual rr[15] and (joc != nullptr) the 15 x nb Jacobian
+// [joca | jocb | jocg] (row-major, ld = nb, must come in zeroed).  Host and device.
+VBH_HD inline void imu_residual_jacobian(const ImuPre &m, const State &s1, const State &s2, bool with_g, double *rr, double *joc, int nb) {
   double rb[3], Eb[9], Rc[9];
   m3_vec(m.R_bg, m.dbg, rb);
   so3_exp(rb, Eb);
@@ -319,7 +326,7 @@ inline double imu_evaluate(const ImuPre &m, const State &s1, const State &s2, bo
   }
   m3_Tvec(s1.R, dv, exp_v);
   m3_Tvec(s1.R, dp, exp_t);
-  double rr[15], lr[3];
+  double lr[3];
   so3_log(res_r, lr);
   for (int i = 0; i < 3; i++) {
     rr[i] = lr[i];
@@ -328,41 +335,51 @@ inline double imu_evaluate(const ImuPre &m, const State &s1, const State &s2, bo
     rr[9 + i] = s2.bg[i] - s1.bg[i];
     rr[12 + i] = s2.ba[i] - s1.ba[i];
   }
-  double cinv[225];
-  inverse_pplu(m.cov, cinv, 15);
+  if (!joc) return;
+  double JRi[9], R2tR1[9], M1[9], M2[9], M3[9], R1t[9], H[9], I3[9];
+  m3_identity(I3);
+  so3_jr_inv(res_r, JRi);
+  m3_Tmul(s2.R, s1.R, R2tR1);
+  m3_mul(JRi, R2tR1, M1);
+  set_block3(joc, nb, 0, 0, M1, -1.0);                 // joca(0,0) = -JR_inv * R2^T * R1
+  set_block3(joc, nb, 0, 15, JRi, 1.0);                // jocb(0,0) = JR_inv
+  double jrb[9], resT[9];
+  so3_jr(rb, jrb);
+  m3_transpose(res_r, resT);
+  m3_mul(JRi, resT, M1); m3_mul(M1, jrb, M2); m3_mul(M2, m.R_bg, M3);
+  set_block3(joc, nb, 0, 9, M3, -1.0);                 // joca(0,9)
+  m3_transpose(s1.R, R1t);
+  hat(exp_t, H); set_block3(joc, nb, 3, 0, H, 1.0);
+  set_block3(joc, nb, 3, 3, R1t, -1.0);
+  set_block3(joc, nb, 3, 6, R1t, -dt);
+  set_block3(joc, nb, 3, 9, m.p_bg, -1.0);
+  set_block3(joc, nb, 3, 12, m.p_ba, -1.0);
+  set_block3(joc, nb, 3, 15 + 3, R1t, 1.0);
+  hat(exp_v, H); set_block3(joc, nb, 6, 0, H, 1.0);
+  set_block3(joc, nb, 6, 6, R1t, -1.0);
+  set_block3(joc, nb, 6, 9, m.v_bg, -1.0);
+  set_block3(joc, nb, 6, 12, m.v_ba, -1.0);
+  set_block3(joc, nb, 6, 15 + 6, R1t, 1.0);
+  set_block3(joc, nb, 9, 9, I3, -1.0); set_block3(joc, nb, 12, 12, I3, -1.0);
+  set_block3(joc, nb, 9, 15 + 9, I3, 1.0); set_block3(joc, nb, 12, 15 + 12, I3, 1.0);
+  if (with_g) { set_block3(joc, nb, 3, 30, R1t, -0.5 * dt * dt); set_block3(joc, nb, 6, 30, R1t, -dt); }
+}
+
+// PI:137-212 / PI:214-294.  jtj (nb x nb), gg (nb), nb = 30 (+3 with gravity).  Returns r^T cov^-1 r.
+// cinv_in: cov^-1 when the caller already holds it (cov does not change inside damping_iter), else nullptr.
+inline double imu_evaluate(const ImuPre &m, const State &s1, const State &s2, bool with_g, bool jac, double *jtj, double *gg,
+                           const double *cinv_in = nullptr) {
+  const int nb = with_g ? 33 : 30;
+  double rr[15];
+  std::vector<double> joc;
+  if (jac) joc.assign((size_t)15 * nb, 0.0);
+  imu_residual_jacobian(m, s1, s2, with_g, rr, jac ? joc.data() : nullptr, nb);
+  double cinv_loc[225];
+  const double *cinv = cinv_in;
+  if (!cinv) { inverse_pplu(m.cov, cinv_loc, 15); cinv = cinv_loc; }
   double cr[15];
   for (int r = 0; r < 15; r++) { double s = 0; for (int k = 0; k < 15; k++) s += cinv[r * 15 + k] * rr[k]; cr[r] = s; }
   if (jac) {
-    const int nb = with_g ? 33 : 30;
-    std::vector<double> joc((size_t)15 * nb, 0.0);
-    auto blk = [&](int r0, int c0, const double *B, double sc) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) joc[(r0 + r) * nb + c0 + c] = sc * B[3 * r + c]; };
-    double JRi[9], R2tR1[9], M1[9], M2[9], M3[9], R1t[9], H[9], I3[9];
-    m3_identity(I3);
-    so3_jr_inv(res_r, JRi);
-    m3_Tmul(s2.R, s1.R, R2tR1);
-    m3_mul(JRi, R2tR1, M1);
-    blk(0, 0, M1, -1.0);                               // joca(0,0) = -JR_inv * R2^T * R1
-    blk(0, 15, JRi, 1.0);                              // jocb(0,0) = JR_inv
-    double jrb[9], resT[9];
-    so3_jr(rb, jrb);
-    m3_transpose(res_r, resT);
-    m3_mul(JRi, resT, M1); m3_mul(M1, jrb, M2); m3_mul(M2, m.R_bg, M3);
-    blk(0, 9, M3, -1.0);                               // joca(0,9)
-    m3_transpose(s1.R, R1t);
-    hat(exp_t, H); blk(3, 0, H, 1.0);
-    blk(3, 3, R1t, -1.0);
-    blk(3, 6, R1t, -dt);
-    blk(3, 9, m.p_bg, -1.0);
-    blk(3, 12, m.p_ba, -1.0);
-    blk(3, 15 + 3, R1t, 1.0);
-    hat(exp_v, H); blk(6, 0, H, 1.0);
-    blk(6, 6, R1t, -1.0);
-    blk(6, 9, m.v_bg, -1.0);
-    blk(6, 12, m.v_ba, -1.0);
-    blk(6, 15 + 6, R1t, 1.0);
-    blk(9, 9, I3, -1.0); blk(12, 12, I3, -1.0);
-    blk(9, 15 + 9, I3, 1.0); blk(12, 15 + 12, I3, 1.0);
-    if (with_g) { blk(3, 30, R1t, -0.5 * dt * dt); blk(6, 30, R1t, -dt); }
     std::vector<double> cj((size_t)15 * nb);
     mat_mul(cinv, joc.data(), cj.data(), 15, 15, nb);
     for (int r = 0; r < nb; r++) {

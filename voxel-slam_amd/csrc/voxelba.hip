@@ -7,6 +7,7 @@
 #include "vba_kernels_factor.hpp"
 #include "vba_kernels_map.hpp"
 #include "vba_kernels_lm.hpp"
+#include "vba_kernels_li.hpp"
 #include "vba_kernels_scan.hpp"
 #include "vba_kernels_gba.hpp"
 #include <cstddef>
@@ -78,6 +79,10 @@ struct vba_ctx {
   double *d_raw = nullptr;        // last valid all-reduced [H|g|r] (multi-rank only; single rank reads d_out in place)
   struct { bool active = false; int thd_num = 2; } lm;
   std::vector<double> trace;
+
+  // device-resident LI-BA (vba_kernels_li.hpp)
+  LiDev *d_li = nullptr;
+  double *d_imu = nullptr, *d_himu = nullptr, *d_gimu = nullptr;
 
   MapStore map;
   GbaStore gba;
@@ -418,6 +423,10 @@ void vba_destroy(vba_ctx *c) {
   map_free(c->map);
   c->gba.free_all();
   if (c->d_refpts) hipFree(c->d_refpts);
+  if (c->d_li) hipFree(c->d_li);
+  if (c->d_imu) hipFree(c->d_imu);
+  if (c->d_himu) hipFree(c->d_himu);
+  if (c->d_gimu) hipFree(c->d_gimu);
   double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out, c->d_full, c->d_scal};
   for (double *q : p) if (q) hipFree(q);
   if (c->d_stage) hipFree(c->d_stage);
@@ -664,8 +673,131 @@ int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
   return n;
 }
 
+// ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity on the device
+extern "C++" {
+template <int W>
+static void launch_li_solve(vba_ctx *c, int copy_raw) {
+  constexpr int NT = 1024, NMAX = 15 * W + 3, MMAX = NMAX * (NMAX + 3) / 2;
+  constexpr size_t lds = ((size_t)MMAX + 2 * (NMAX + 1) + 5 * NMAX + 2) * 8 + (size_t)(2 * NMAX + 2) * 4 + 64;
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL((k_li_solve<W, NT>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu);
+}
+}  // extern "C++"
+
+static bool li_device_supported(int W) { return W == 2 || W == 3 || W == 4 || W == 5 || W == 6 || W == 8 || W == 10; }
+
+static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
+  const int W = c->opt.win_size, V = c->nvox, DIM = VBA_DIM, F = W - 1;
+  const int n = W * DIM + (gravity ? 3 : 0), nb = gravity ? 33 : 30, n6 = 6 * W;
+  if (!gravity) max_iter = 3;                                         // VM:643
+  if (!c->d_li) {
+    HIPCHK(c, hipMalloc((void **)&c->d_li, sizeof(LiDev)));
+    HIPCHK(c, hipMalloc((void **)&c->d_imu, (size_t)LI_MAX_W * 304 * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_himu, (size_t)LI_MAX_N * LI_MAX_N * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_gimu, (size_t)LI_MAX_N * sizeof(double)));
+  }
+  // upload: LM state (poses view), the IMU extras, the factors with cov^-1 in place of cov
+  std::vector<double> poses((size_t)W * 12);
+  states_to_poses(states, W, poses.data());
+  int st = vba_lm_begin(c, poses.data(), 0);
+  if (st) return st;
+  LiDev h{};
+  h.W = W; h.n = n; h.nb = nb; h.gravity = gravity ? 1 : 0; h.gauge = gravity ? 6 : DIM; h.F = F; h.imu_coef = c->opt.imu_coef;   // VM:653-656 / 906-909
+  for (int i = 0; i < W; i++) {
+    const double *sx = states + 25 * i;
+    h.tstamp[i] = sx[0];
+    for (int k = 0; k < 12; k++) h.ex[12 * i + k] = h.ext[12 * i + k] = sx[13 + k];
+  }
+  std::vector<double> fimg((size_t)F * 304);
+  std::memcpy(fimg.data(), imus, fimg.size() * sizeof(double));
+  for (int f = 0; f < F; f++) vbh::inverse_pplu(imus + 304 * (size_t)f + 79, fimg.data() + 304 * (size_t)f + 79, 15);   // PI:166 / 244
+  HIPCHK(c, hipMemcpyAsync(c->d_li, &h, sizeof(LiDev), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_imu, fimg.data(), fimg.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_himu, 0, (size_t)n * n * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_gimu, 0, (size_t)n * sizeof(double), c->stream));
+  char *base = reinterpret_cast<char *>(c->d_lm);
+  const double *x_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, x));
+  const double *xt_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, xt));
+  const int *run_hess = reinterpret_cast<const int *>(base + offsetof(LmDev, run_hess));
+  const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
+  const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
+  const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16) * sizeof(double);
+  for (int it = 0; it < max_iter; it++) {
+    st = hessian_pass(c, x_dev, run_hess, 0, V);                      // lidar part of divide_thread (+ all-reduce)
+    if (st) { c->lm.active = false; return st; }
+    TimedSpan s0{}, s1{};
+    span_begin(c, "imu", s0);
+    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
+    span_end(c, "imu", s0);
+    span_begin(c, "solve", s1);
+    switch (W) {
+      case 2: launch_li_solve<2>(c, copy_raw); break;
+      case 3: launch_li_solve<3>(c, copy_raw); break;
+      case 4: launch_li_solve<4>(c, copy_raw); break;
+      case 5: launch_li_solve<5>(c, copy_raw); break;
+      case 6: launch_li_solve<6>(c, copy_raw); break;
+      case 8: launch_li_solve<8>(c, copy_raw); break;
+      case 10: launch_li_solve<10>(c, copy_raw); break;
+      default: c->lm.active = false; return VBA_ERR_UNSUPPORTED_WINDOW;
+    }
+    span_end(c, "solve", s1);
+    if (copy_raw || V == 0) {
+      st = residual_pass(c, xt_dev, run_res, 0, V, c->d_scal);        // lidar part of only_residual (+ scalar all-reduce)
+      if (st) { c->lm.active = false; return st; }
+      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_scal, 0);
+    } else {
+      const int nbk = (V + 63) / 64;
+      TimedSpan s2{};
+      span_begin(c, "residual", s2);
+      launch_residual(c, xt_dev, run_res, 0, V, nbk);
+      span_end(c, "residual", s2);
+      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_partial, nbk);
+    }
+    HIPCHK(c, hipGetLastError());
+  }
+  // download: accepted state, the factors' bias increments, trace, and (on request) *hess = Hess before gauge fixing
+  std::vector<double> himu;
+  st = ensure_pin(c, 65536 + (size_t)n6 * n6 + 1024);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&h, c->d_li, sizeof(LiDev), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(fimg.data(), c->d_imu, fimg.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (hess) {
+    himu.resize((size_t)n * n);
+    st = tiles_to_full(c, copy_raw ? c->d_raw : c->d_out);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, c->d_full, (size_t)n6 * n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(himu.data(), c->d_himu, himu.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->lm.active = false;
+  const LmDev *hl = c->h_lm;
+  for (int i = 0; i < W; i++) {
+    double *sx = states + 25 * i;
+    for (int k = 0; k < 12; k++) sx[1 + k] = hl->x[12 * i + k];
+    for (int k = 0; k < 12; k++) sx[13 + k] = h.ex[12 * i + k];
+  }
+  for (int f = 0; f < F; f++) std::memcpy(imus + 304 * (size_t)f + 67, fimg.data() + 304 * (size_t)f + 67, 12 * sizeof(double));   // dbg, dba, dbg_buf, dba_buf
+  if (hess) {
+    const double *lid = c->h_pin + 32768;
+    for (size_t t = 0; t < himu.size(); t++) hess[t] = c->opt.imu_coef * himu[t];                                                   // VM:565
+    for (int i = 0; i < W; i++)
+      for (int j = 0; j < W; j++)
+        for (int r = 0; r < 6; r++)
+          for (int k = 0; k < 6; k++) hess[(size_t)(i * DIM + r) * n + j * DIM + k] += lid[(size_t)(i * 6 + r) * n6 + j * 6 + k];   // hess_plus VM:509-517
+  }
+  if (gravity && resis2) { resis2[0] = hl->resis_first; resis2[1] = hl->r2; }
+  c->trace.assign(hl->trace, hl->trace + 5 * hl->n_trace);
+  return VBA_OK;
+}
+
 // ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity (VM:504-976)
 int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
+  {
+    static const bool force_host = getenv("VBA_LI_HOST") != nullptr;     // diagnostic: the earlier host-side IMU + solve
+    if (!force_host && li_device_supported(c->opt.win_size)) return li_ba_device(c, states, imus, gravity, max_iter, hess, resis2);
+  }
   const int W = c->opt.win_size, n6 = 6 * W, nout = nout_of(W), V = c->nvox;
   const int DIM = VBA_DIM;
   const int imu_leng = W * DIM + (gravity ? 3 : 0);
