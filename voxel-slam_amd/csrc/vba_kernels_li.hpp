@@ -49,12 +49,14 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
     vbh::imu_residual_jacobian(*reinterpret_cast<const vbh::ImuPre *>(imu + 304 * (size_t)tid), s1, s2, grav != 0, rr + 15 * tid, joc + (size_t)tid * 15 * nb, nb);
   }
   __syncthreads();
-  for (int t = tid; t < F * 15 * nb; t += 256) {            // cj_f = cov^-1 joc_f
-    const int f = t / (15 * nb), k = (t / nb) % 15, c = t % nb;
-    const double *ci = imu + 304 * (size_t)f + 79 + 15 * k, *jf = joc + (size_t)f * 15 * nb;
-    double a = 0;
-    for (int k2 = 0; k2 < 15; k2++) a += ci[k2] * jf[k2 * nb + c];
-    cj[t] = a;
+  for (int f = 0; f < F; f++) {                              // cj_f = cov^-1 joc_f
+    const double *jf = joc + (size_t)f * 15 * nb, *cv = imu + 304 * (size_t)f + 79;
+    for (int t = tid; t < 15 * nb; t += 256) {
+      const int k = t / nb, c = t - k * nb;
+      double a = 0;
+      for (int k2 = 0; k2 < 15; k2++) a += cv[15 * k + k2] * jf[k2 * nb + c];
+      cj[(size_t)f * 15 * nb + t] = a;
+    }
   }
   if (tid < F * 15) {
     const int f = tid / 15, k = tid % 15;
@@ -65,43 +67,57 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
   }
   __syncthreads();
   if (tid < F) { double q = 0; for (int k = 0; k < 15; k++) q += rr[15 * tid + k] * cr[15 * tid + k]; qf[tid] = q; }
-  // entries: [0, NE1) state blocks (a, b = a-1..a+1), then gravity border, then g
-  const int npair = 3 * W - 2, NE1 = npair * 225, NEG = grav ? (2 * 15 * W * 3 + 9) : 0, NG = n;
-  for (int e = tid; e < NE1 + NEG + NG; e += 256) {
-    int R, C, isg = 0;
-    if (e < NE1) {
-      const int pr = e / 225, r = (e % 225) / 15, c = e % 15;
-      // pair index -> (a, b): a = (pr + 1) / 3, b = a + ((pr + 1) % 3) - 1
-      const int a = (pr + 1) / 3, b = a + ((pr + 1) % 3) - 1;
-      R = 15 * a + r; C = 15 * b + c;
-    } else if (e < NE1 + NEG) {
-      const int q = e - NE1;
-      if (q < 15 * W * 3) { R = q / 3; C = n - 3 + q % 3; }
-      else if (q < 2 * 15 * W * 3) { const int q2 = q - 15 * W * 3; R = n - 3 + q2 % 3; C = q2 / 3; }
-      else { const int q2 = q - 2 * 15 * W * 3; R = n - 3 + q2 / 3; C = n - 3 + q2 % 3; }
-    } else { R = e - NE1 - NEG; C = 0; isg = 1; }
-    // factors touching row R / column C and the local indices inside their 30(+3) window
-    const int aR = R < 15 * W ? R / 15 : -1, aC = C < 15 * W ? C / 15 : -1;
-    double acc = 0;
-    for (int f = 0; f < F; f++) {
-      int lr, lc;
-      if (aR >= 0) { if (aR == f) lr = R - 15 * f; else if (aR == f + 1) lr = 15 + R - 15 * (f + 1); else continue; }
-      else lr = 30 + (R - (n - 3));
-      const double *jf = joc + (size_t)f * 15 * nb;
-      if (isg) {
-        double a = 0;
-        for (int k = 0; k < 15; k++) a += jf[k * nb + lr] * cr[15 * f + k];
-        acc += a;
-        continue;
+  // jtj_f(lr, lc) = sum_k joc_f[k][lr] cj_f[k][lc]
+  auto jtj = [&](int f, int lr, int lc) -> double {
+    const double *jf = joc + (size_t)f * 15 * nb + lr, *cf = cj + (size_t)f * 15 * nb + lc;
+    double a = 0;
+    for (int k = 0; k < 15; k++) a += jf[k * nb] * cf[k * nb];
+    return a;
+  };
+  // state blocks: the (a, b) pair is uniform per iteration, every thread keeps one (r, c) of the 15 x 15 block
+  if (tid < 225) {
+    const int r = tid / 15, c = tid - 15 * r;
+    for (int a = 0; a < W; a++)
+      for (int b = (a > 0 ? a - 1 : 0); b <= (a + 1 < W ? a + 1 : W - 1); b++) {
+        double acc = 0;
+        if (b == a) { if (a >= 1) acc += jtj(a - 1, 15 + r, 15 + c); if (a <= W - 2) acc += jtj(a, r, c); }
+        else if (b == a + 1) acc = jtj(a, r, 15 + c);
+        else acc = jtj(b, 15 + r, c);
+        himu[(size_t)(15 * a + r) * n + 15 * b + c] = acc;
       }
-      if (aC >= 0) { if (aC == f) lc = C - 15 * f; else if (aC == f + 1) lc = 15 + C - 15 * (f + 1); else continue; }
-      else lc = 30 + (C - (n - 3));
-      const double *cf = cj + (size_t)f * 15 * nb;
-      double a = 0;
-      for (int k = 0; k < 15; k++) a += jf[k * nb + lr] * cf[k * nb + lc];
-      acc += a;
+  }
+  if (grav) {                                                // gravity border VM:788-795 and the 3 x 3 corner
+    for (int e = tid; e < 15 * W * 3; e += 256) {
+      const int R = e / 3, k = e - 3 * R, a = R / 15, r = R - 15 * a;
+      double u1 = 0, u2 = 0;
+      if (a >= 1) { u1 += jtj(a - 1, 15 + r, 30 + k); u2 += jtj(a - 1, 30 + k, 15 + r); }
+      if (a <= W - 2) { u1 += jtj(a, r, 30 + k); u2 += jtj(a, 30 + k, r); }
+      himu[(size_t)R * n + n - 3 + k] = u1;
+      himu[(size_t)(n - 3 + k) * n + R] = u2;
     }
-    if (isg) gimu[R] = acc; else himu[(size_t)R * n + C] = acc;
+    if (tid < 9) {
+      const int r = tid / 3, k = tid - 3 * r;
+      double acc = 0;
+      for (int f = 0; f < F; f++) acc += jtj(f, 30 + r, 30 + k);
+      himu[(size_t)(n - 3 + r) * n + n - 3 + k] = acc;
+    }
+  }
+  if (tid < n) {                                             // gradient: gg_f(lr) = sum_k joc_f[k][lr] cr_f[k]
+    auto gg = [&](int f, int lr) -> double {
+      const double *jf = joc + (size_t)f * 15 * nb + lr;
+      double a = 0;
+      for (int k = 0; k < 15; k++) a += jf[k * nb] * cr[15 * f + k];
+      return a;
+    };
+    double acc = 0;
+    if (tid < 15 * W) {
+      const int a = tid / 15, r = tid - 15 * a;
+      if (a >= 1) acc += gg(a - 1, 15 + r);
+      if (a <= W - 2) acc += gg(a, r);
+    } else {
+      for (int f = 0; f < F; f++) acc += gg(f, 30 + (tid - 15 * W));
+    }
+    gimu[tid] = acc;
   }
   __syncthreads();
   if (tid == 0) { double q = 0; for (int f = 0; f < F; f++) q += qf[f]; li->rimu[0] = q; }
@@ -114,82 +130,152 @@ __device__ __forceinline__ double li_hfull(const double *__restrict__ himu, cons
   if (r < 15 * W && c < 15 * W) { const int a = r / 15, lr = r - 15 * a, b = c / 15, lc = c - 15 * b; if (lr < 6 && lc < 6) v += tl_fetch<W>(src, 6 * a + lr, 6 * b + lc); }
   return v;
 }
-// element e of the packed, permuted, gauged and damped system (row n = right-hand side)
-template <int W>
-__device__ __forceinline__ double li_elem_init(int e, int n, int gauge, double u, double coef, const double *__restrict__ himu,
-                                                        const double *__restrict__ src, const double *gs, const int *ord, const int *off, int *ij) {
-  int lo = 0, hi = n;                          // largest j with off[j] <= e
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= e) lo = mid; else hi = mid; }
-  const int j = lo, i = j + (e - off[j]);
-  *ij = (i << 16) | j;
-  const int pj = ord[j];
-  if (i == n) return -gs[pj];
-  const int pi = ord[i];
-  const int rr = pi > pj ? pi : pj, cc = pi > pj ? pj : pi;
-  double a = (rr < gauge || cc < gauge) ? ((rr == cc) ? 1.0 : 0.0) : li_hfull<W>(himu, src, coef, n, rr, cc);
-  if (i == j) a += u * a;
-  return a;
+// ------------------------------------------------------------------------------------------------
+// Blocked LDL^T of a symmetric NP x NP system (NP a multiple of 16) by ONE workgroup, trailing matrix resident in MFMA
+// accumulators.  Pivoting is static (the caller passes the matrix already permuted), which is what Eigen's LDLT amounts
+// to once the order "largest |stored diagonal| first" has been fixed.
+//   * the lower triangle lives as 16x16 f64 accumulator tiles (v_mfma_f64_16x16x4_f64 layout: lane l holds rows
+//     (l >> 4) + 4 r, column l & 15), tiles dealt round-robin to the waves, longest-living tile columns first;
+//   * per panel of 8 columns: the owners publish the panel P[row][8] to LDS; every row-lane factorises the 8x8 diagonal
+//     block REDUNDANTLY in registers (no communication on the pivot chain) and forward-substitutes its own row, writing
+//     L (kept for the back substitution, column blocks of 8, row stride 9 doubles: conflict-free operand reads) and
+//     -T = -L D; two MFMAs per live tile apply the rank-8 update C += L (-T)^T;
+//   * two barriers per panel instead of one or two per column.
+// A right-hand side carried as an extra ROW (rhs_row) leaves D^-1 L^-1 b in that row of L.
+// Zero pivots follow Eigen (ldlt_inplace: a column with |d| == 0 is left unscaled; solve(): |d| <= DBL_MIN gives 0).
+template <int NP>
+struct LdltCfg {
+  static constexpr int NTL = NP / 16, NTILES = NTL * (NTL + 1) / 2, NBLK = NP / 8, LS = 9;
+  static constexpr int LTOT = LS * 4 * NBLK * (NBLK + 1);                       // sum over panels of (NP - 8 kb) rows x LS
+  __host__ __device__ static constexpr int lst_off(int kb) { return LS * 8 * (kb * NBLK - kb * (kb - 1) / 2); }
+  static constexpr int DOUBLES = LTOT + NP * LS + NP * 8;                       // Lst | Tp | P
+  __device__ static __forceinline__ int lat(int j, int i) { return lst_off(i >> 3) + (j - (i & ~7)) * LS + (i & 7); }   // L[j][i], j > i
+};
+
+template <int NP, int NT, typename F>
+__device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__restrict__ Tp, double *__restrict__ P, int rhs_row, F elem) {
+  using C = LdltCfg<NP>;
+  constexpr int NW = NT / 64, TPW = (C::NTILES + NW - 1) / NW, LS = C::LS;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, lr = l >> 4, lc = l & 15;
+  // tile t (ordered by tile column descending, then tile row) -> (ti, tj); wave w owns t = w, w + NW, ...
+  int tti[TPW], ttj[TPW];
+  v4f64 acc[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; u++) {
+    const int t = w + NW * u;
+    int tj = C::NTL - 1, rem = t;
+    while (tj > 0 && rem >= C::NTL - tj) { rem -= C::NTL - tj; tj--; }          // column tj has NTL - tj tiles
+    tti[u] = tj + rem; ttj[u] = tj;
+    if (t < C::NTILES) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[u][r] = elem(16 * tti[u] + lr + 4 * r, 16 * ttj[u] + lc);
+      if (ttj[u] == 0 && lc < 8)
+#pragma unroll
+        for (int r = 0; r < 4; r++) P[(16 * tti[u] + lr + 4 * r) * 8 + lc] = acc[u][r];
+    }
+  }
+  for (int kb = 0; kb < C::NBLK; kb++) {
+    const int k0 = 8 * kb;
+    double *Lk = Lst + C::lst_off(kb);
+    __syncthreads();
+    if (tid < NP && tid >= k0) {
+      const int i = tid, ib = i - k0;
+      double D[8][8], dd[8], dinv[8], x[8], tm[8];
+      bool ok[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) D[r][c] = P[(k0 + r) * 8 + c];
+      {
+        const double2 x0 = *reinterpret_cast<const double2 *>(P + i * 8), x1 = *reinterpret_cast<const double2 *>(P + i * 8 + 2),
+                      x2 = *reinterpret_cast<const double2 *>(P + i * 8 + 4), x3 = *reinterpret_cast<const double2 *>(P + i * 8 + 6);
+        x[0] = x0.x; x[1] = x0.y; x[2] = x1.x; x[3] = x1.y; x[4] = x2.x; x[5] = x2.y; x[6] = x3.x; x[7] = x3.y;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {            // right-looking elimination of the diagonal block, identical in every lane
+        const double d = D[c][c];
+        ok[c] = fabs(d) > 0.0;
+        double inv = __builtin_amdgcn_rcp(d);
+        inv = fma(fma(-d, inv, 1.0), inv, inv);
+        inv = fma(fma(-d, inv, 1.0), inv, inv);
+        dd[c] = d; dinv[c] = ok[c] ? inv : 0.0;
+#pragma unroll
+        for (int r = c + 1; r < 8; r++) D[r][c] = ok[c] ? D[r][c] * inv : D[r][c];      // L[r][c]
+#pragma unroll
+        for (int r = c + 1; r < 8; r++) {
+          const double t = D[r][c] * d;                                                  // T[r][c]
+#pragma unroll
+          for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] -= t * D[c2][c];
+        }
+      }
+      const bool is_rhs = (i == rhs_row);
+#pragma unroll
+      for (int c = 0; c < 8; c++) {            // this lane's row against the block: l_c = (x_c - sum_m t_m Ld[c][m]) / d_c
+        double sacc = x[c];
+#pragma unroll
+        for (int m = 0; m < c; m++) sacc -= tm[m] * D[c][m];
+        double lv = ok[c] ? sacc * dinv[c] : sacc;
+        if (is_rhs) lv = (fabs(dd[c]) > 2.2250738585072014e-308) ? sacc * dinv[c] : 0.0;
+        lv = (ib > c) ? lv : 0.0;             // rows of the diagonal block: strictly lower part only
+        tm[c] = lv * dd[c];
+        Lk[ib * LS + c] = lv;
+        Tp[i * LS + c] = -tm[c];
+      }
+    }
+    __syncthreads();
+    const int kn = k0 + 8;
+    if (kn >= NP) break;
+    const int tjn = kn >> 4, cb0 = kn & 15;
+#pragma unroll
+    for (int u = 0; u < TPW; u++) {
+      const int t = w + NW * u;
+      if (t < C::NTILES && ttj[u] >= tjn) {    // wave-uniform
+        const double *la = Lk + (16 * tti[u] + lc - k0) * LS + lr, *tb = Tp + (16 * ttj[u] + lc) * LS + lr;
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[0], tb[0], acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[4], tb[4], acc[u], 0, 0, 0);
+        if (ttj[u] == tjn && lc >= cb0 && lc < cb0 + 8)
+#pragma unroll
+          for (int r = 0; r < 4; r++) P[(16 * tti[u] + lr + 4 * r) * 8 + (lc - cb0)] = acc[u][r];
+      }
+    }
+  }
+  __syncthreads();
 }
 
-// The elements a thread owns, as a compile-time recursion: every member is its own scalar (an indexed register array
-// here turned into one 32-register tuple that was copied and spilled on every branch: 1600 spill instructions).
-// Elements are dealt in packed order, so a thread's list is sorted by column: those with j > k form a suffix.
-template <int Q, int NT>
-struct LiElems {
-  double v; int i, j;
-  LiElems<Q - 1, NT> next;
-  __device__ __forceinline__ void init(int e, int M, int n, const int *off, const double *Lm) {
-    i = n; j = n; v = 0.0;                      // unused slot: never published, its dummy update reads cb[n]
-    if (e < M) {
-      int lo = 0, hi = n;                       // largest column with off[col] <= e
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= e) lo = mid; else hi = mid; }
-      j = lo; i = lo + (e - off[lo]);
-      v = Lm[e];
-    }
-    next.init(e + NT, M, n, off, Lm);
-  }
-  __device__ __forceinline__ void publish(int k, double *cb) const { if (j == k) cb[i] = v; next.publish(k, cb); }
-  // returns false once an element with j < k has been met (everything before it is finished too)
-  __device__ __forceinline__ bool update(int k, int n, int e, const double *cb, double inv, bool ok, double invz, double *Lm) {
-    if (!next.update(k, n, e + NT, cb, inv, ok, invz, Lm)) return false;
-    if (j < k) return false;
-    if (j == k) {
-      if (i != k) {
-        const double l = (i == n) ? v * invz : (ok ? v * inv : v);
-        v = l; Lm[e] = l;
+// x = L^-T z for the first n rows (z in xs on entry, x in xs on exit), 64 rows per wave, blocks from the bottom.
+template <int NP>
+__device__ __forceinline__ double ldlt_backsub(const double *__restrict__ Lst, double *__restrict__ xs, int n) {
+  using C = LdltCfg<NP>;
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const int nblk = (n + 63) >> 6;
+  double x = (tid < n) ? xs[tid] : 0.0;
+  for (int b = nblk - 1; b >= 0; b--) {
+    const int hiR = (64 * b + 63 < n - 1) ? 64 * b + 63 : n - 1;
+    if (wv == b) {
+      for (int j = hiR; j > 64 * b; j--) {
+        const double xj = readlane_f64(x, j - 64 * b);
+        if (tid < j && tid < n) x -= Lst[C::lat(j, tid)] * xj;
       }
-    } else {
-      v -= cb[i] * (cb[j] * inv);
+      if (tid < n) xs[tid] = x;
     }
-    return true;
+    __syncthreads();
+    if (wv < b && tid < n)
+      for (int j = 64 * b; j <= hiR; j++) x -= Lst[C::lat(j, tid)] * xs[j];
   }
-  __device__ __forceinline__ void emit_rhs(int n, double *xs) const { if (i == n && j < n) xs[j] = v; next.emit_rhs(n, xs); }
-};
-template <int NT>
-struct LiElems<0, NT> {
-  __device__ __forceinline__ void init(int, int, int, const int *, const double *) {}
-  __device__ __forceinline__ void publish(int, double *) const {}
-  __device__ __forceinline__ bool update(int, int, int, const double *, double, bool, double, double *) { return true; }
-  __device__ __forceinline__ void emit_rhs(int, double *) const {}
-};
+  return x;
+}
 
-// (H + u D) dxi = -g for the 15W(+3) system, Eigen-LDLT pivot order (largest |stored diagonal| first), then the
-// retraction of VM:661-671 / 921-934.  One workgroup of NT threads; the lower triangle of the permuted matrix plus the
-// right-hand side as an extra ROW (so that D^-1 L^-1 (-g) falls out of the factorisation) is dealt cyclically to the
-// threads and lives in REGISTERS; per column k the owners publish column k, one barrier, every thread applies the rank-1
-// update to the elements it owns.  L is kept packed in LDS for the back substitution.
+// (H + u D) dxi = -g for the 15W(+3) system in Eigen-LDLT pivot order, then the retraction of VM:661-671 / 921-934.
 template <int W, int NT>
 __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const double *__restrict__ red, double *__restrict__ raw, int copy_raw,
                                                  const double *__restrict__ himu, const double *__restrict__ gimu, double *__restrict__ imu) {
   using C2 = HessCfg2<W>;
-  constexpr int NMAX = 15 * W + 3;
-  constexpr int MMAX = NMAX * (NMAX + 3) / 2;
-  constexpr int Q = (MMAX + NT - 1) / NT;
+  constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
+  using LC = LdltCfg<NP>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *Lm = lds;                              // [MMAX] packed columns: column j holds rows j..n (row n = rhs)
-  double *colbuf = Lm + MMAX;                    // [2][NMAX + 1]
-  double *hd = colbuf + 2 * (NMAX + 1), *gs = hd + NMAX, *dsh = gs + NMAX, *xs = dsh + NMAX, *dxs = xs + NMAX + 1;
-  int *ord = (int *)(dxs + NMAX), *off = ord + NMAX;      // off[j] = first packed index of column j, off[n] = M
+  double *Lst = lds, *Tp = Lst + LC::LTOT, *P = Tp + NP * LC::LS;
+  double *hd = P + NP * 8, *gs = hd + NMAX, *dsh = gs + NMAX, *xs = dsh + NMAX, *dxs = xs + NP, *red8 = dxs + NMAX;
+  int *ord = (int *)(red8 + 32);
   const int tid = threadIdx.x;
   if (s->stop) return;
   const int n = li->n, gauge = li->gauge, calc = s->is_calc_hess, iter0 = s->iter, grav = li->gravity;
@@ -207,7 +293,6 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
     }
     hd[tid] = h; gs[tid] = g; dsh[tid] = fabs(h + u * h);
   }
-  if (tid <= n) off[tid] = tid * (n + 1) - tid * (tid - 1) / 2;
   __syncthreads();
   if (tid < n) {
     const double me = dsh[tid];
@@ -216,51 +301,26 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
     ord[rank] = tid;
   }
   __syncthreads();
-  const int M = off[n];
-  // stage the system through LDS with a ROLLED loop (the gather from the tile layout is register hungry), then deal the
-  // elements to registers with a light unrolled loop; Lm[e] is overwritten by the final L value of the same element later
-  for (int e = tid; e < M; e += NT) { int ij; Lm[e] = li_elem_init<W>(e, n, gauge, u, coef, himu, src, gs, ord, off, &ij); }
+  // element (i, j) of the padded system: P (H + u D) P^T lower triangle, row n = -g, identity on the padding
+  auto elem = [&](int i, int j) -> double {
+    if (j >= n) return (i == j) ? 1.0 : 0.0;
+    if (i > n || i < j) return 0.0;
+    const int pj = ord[j];
+    if (i == n) return -gs[pj];
+    const int pi = ord[i];
+    const int rr = pi > pj ? pi : pj, cc = pi > pj ? pj : pi;
+    double a = (rr < gauge || cc < gauge) ? ((rr == cc) ? 1.0 : 0.0) : li_hfull<W>(himu, src, coef, n, rr, cc);
+    if (i == j) a += u * a;
+    return a;
+  };
+  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem);
+  if (tid < n) xs[tid] = Lst[LC::lat(n, tid)];                                  // z = D^-1 L^-1 P (-g)
   __syncthreads();
-  LiElems<Q, NT> el;
-  el.init(tid, M, n, off, Lm);
-  for (int k = 0; k < n; k++) {
-    double *cb = colbuf + (k & 1) * (NMAX + 1);
-    el.publish(k, cb);
-    __syncthreads();
-    const double dk = cb[k];
-    const bool ok = fabs(dk) > 0.0;
-    double inv = __builtin_amdgcn_rcp(dk);
-    inv = fma(fma(-dk, inv, 1.0), inv, inv);
-    inv = fma(fma(-dk, inv, 1.0), inv, inv);
-    if (!ok) inv = 0.0;
-    const double invz = (fabs(dk) > 2.2250738585072014e-308) ? inv : 0.0;      // D^-1 y with Eigen's tolerance (rhs row)
-    el.update(k, n, tid, cb, inv, ok, invz, Lm);
-  }
-  el.emit_rhs(n, xs);                                                          // z = D^-1 L^-1 P (-g)
-  __syncthreads();
-  // x = L^-T z, 64 rows per wave, blocks from the bottom
-  const int nblk = (n + 63) >> 6, wv = tid >> 6, lane = tid & 63;
-  double x = (tid < n) ? xs[tid] : 0.0;
-  for (int b = nblk - 1; b >= 0; b--) {
-    if (wv == b) {
-      const int hiR = (64 * b + 63 < n - 1) ? 64 * b + 63 : n - 1;
-      for (int j = hiR; j > 64 * b; j--) {
-        const double xj = readlane_f64(x, j - 64 * b);
-        if (tid < j && tid < n) x -= Lm[off[tid] + (j - tid)] * xj;
-      }
-      if (tid < n) xs[tid] = x;
-    }
-    __syncthreads();
-    if (wv < b && tid < n) {
-      const int hiR = (64 * b + 63 < n - 1) ? 64 * b + 63 : n - 1;
-      const double *col = Lm + off[tid] - tid;
-      for (int j = 64 * b; j <= hiR; j++) x -= col[j] * xs[j];
-    }
-  }
+  const double x = ldlt_backsub<NP>(Lst, xs, n);
   if (tid < n) dxs[ord[tid]] = x;
   __syncthreads();
   // retraction VM:661-671 / 921-934 and the bias increments of IMU_PRE::update_state (PI:296-303)
-  double *gl = colbuf + 32;                                          // (colbuf is free again)
+  double *gl = red8 + 16;
   if (grav && tid < 3) { const double gn = li->ext[9 + tid] + dxs[n - 3 + tid]; gl[tid] = gn; }   // accumulates on x_stats_temp[0].g (VM:921)
   __syncthreads();
   if (tid < W) {
@@ -284,9 +344,9 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   }
   double q = tid < n ? dxs[tid] * (u * hd[tid] * dxs[tid] - gs[tid]) : 0.0;            // VM:673
   for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-  if (lane == 0) colbuf[wv] = q;
+  if ((tid & 63) == 0) red8[tid >> 6] = q;
   __syncthreads();
-  if (tid == 0) { double t = 0; for (int w2 = 0; w2 < NT / 64; w2++) t += colbuf[w2]; s->q1 = 0.5 * t; }
+  if (tid == 0) { double t = 0; for (int w2 = 0; w2 < NT / 64; w2++) t += red8[w2]; s->q1 = 0.5 * t; }
 }
 
 // only_residual's IMU part at the trial states (VM:605-607 / 851-854) + the accept / reject bookkeeping of VM:675-706.

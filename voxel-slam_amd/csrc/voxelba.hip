@@ -675,10 +675,10 @@ int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
 
 // ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity on the device
 extern "C++" {
-template <int W>
+template <int W, int NT = 512>
 static void launch_li_solve(vba_ctx *c, int copy_raw) {
-  constexpr int NT = 1024, NMAX = 15 * W + 3, MMAX = NMAX * (NMAX + 3) / 2;
-  constexpr size_t lds = ((size_t)MMAX + 2 * (NMAX + 1) + 5 * NMAX + 2) * 8 + (size_t)(2 * NMAX + 2) * 4 + 64;
+  constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
+  constexpr size_t lds = ((size_t)LdltCfg<NP>::DOUBLES + 4 * NMAX + NP + 32) * 8 + (size_t)NMAX * 4 + 64;
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL((k_li_solve<W, NT>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu);
@@ -738,7 +738,11 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
       case 5: launch_li_solve<5>(c, copy_raw); break;
       case 6: launch_li_solve<6>(c, copy_raw); break;
       case 8: launch_li_solve<8>(c, copy_raw); break;
-      case 10: launch_li_solve<10>(c, copy_raw); break;
+      case 10: {
+        static const int nt = getenv("VBA_LI_NT") ? atoi(getenv("VBA_LI_NT")) : 512;      // tuning knob
+        if (nt == 256) launch_li_solve<10, 256>(c, copy_raw); else if (nt == 1024) launch_li_solve<10, 1024>(c, copy_raw); else launch_li_solve<10, 512>(c, copy_raw);
+        break;
+      }
       default: c->lm.active = false; return VBA_ERR_UNSUPPORTED_WINDOW;
     }
     span_end(c, "solve", s1);
