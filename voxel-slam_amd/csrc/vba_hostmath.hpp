@@ -142,10 +142,16 @@ VBH_HD inline void set_block3(double *M, int ld, int r0, int c0, const double *B
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[(r0 + r) * ld + c0 + c] = scale * B[3 * r + c];
 }
 
-// inverse via LU with partial pivoting (Eigen PartialPivLU path for fixed sizes > 4)
+// inverse via LU with partial pivoting (Eigen PartialPivLU path for fixed sizes > 4); n <= 16 works on the stack
 inline void inverse_pplu(const double *A, double *Ainv, int n) {
-  std::vector<double> lu(A, A + (size_t)n * n);
-  std::vector<int> perm(n);
+  double lu_s[256], y_s[16];
+  int perm_s[16];
+  std::vector<double> lu_v, y_v;
+  std::vector<int> perm_v;
+  double *lu = lu_s, *y = y_s;
+  int *perm = perm_s;
+  if (n > 16) { lu_v.resize((size_t)n * n); y_v.resize(n); perm_v.resize(n); lu = lu_v.data(); y = y_v.data(); perm = perm_v.data(); }
+  for (int i = 0; i < n * n; i++) lu[i] = A[i];
   for (int i = 0; i < n; i++) perm[i] = i;
   for (int k = 0; k < n; k++) {
     int piv = k;
@@ -161,7 +167,6 @@ inline void inverse_pplu(const double *A, double *Ainv, int n) {
       for (int j = k + 1; j < n; j++) lu[i * n + j] -= l * lu[k * n + j];
     }
   }
-  std::vector<double> y(n);
   for (int c = 0; c < n; c++) {
     for (int i = 0; i < n; i++) {
       double s = (perm[i] == c) ? 1.0 : 0.0;

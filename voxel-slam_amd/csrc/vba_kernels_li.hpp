@@ -30,10 +30,25 @@ __device__ __forceinline__ void li_state(const double *pose12, const double *ex1
   for (int k = 0; k < 3; k++) { s.p[k] = pose12[9 + k]; s.v[k] = ex12[k]; s.bg[k] = ex12[3 + k]; s.ba[k] = ex12[6 + k]; s.g[k] = ex12[9 + k]; }
 }
 
+// compact IMU Hessian layout: [pair (a, b), |a - b| <= 1][15][15] | (R, g col k) [15W][3] | (g row k, C) [3][15W] | corner [3][3]
+__host__ __device__ inline int li_hb_pair(int a, int b) { return (3 * a + (b - a)) * 225; }
+__host__ __device__ inline int li_hb_ne1(int W) { return (3 * W - 2) * 225; }
+__host__ __device__ inline int li_hb_size(int W, int grav) { return li_hb_ne1(W) + (grav ? 90 * W + 9 : 0); }
+__host__ __device__ inline double li_hb_get(const double *hb, int W, int n, int R, int C) {   // dense (R, C) from the compact image
+  const int nw = 15 * W;
+  if (R < nw && C < nw) { const int a = R / 15, b = C / 15; if (a - b > 1 || b - a > 1) return 0.0; return hb[li_hb_pair(a, b) + (R - 15 * a) * 15 + (C - 15 * b)]; }
+  const int ne1 = li_hb_ne1(W);
+  if (R < nw) return hb[ne1 + R * 3 + (C - nw)];
+  if (C < nw) return hb[ne1 + 45 * W + (R - nw) * nw + C];
+  return hb[ne1 + 90 * W + (R - nw) * 3 + (C - nw)];
+}
+
 // IMU part of divide_thread (VM:551-567 / 783-801).  imu[f] = the ImuPre image of factor f with `cov` REPLACED by cov^-1
 // (cov is constant inside damping_iter; the host inverts it once per call, preintegration.hpp:166 does it per evaluation).
 // Output-centric: every entry of the block-tridiagonal (+ gravity border) Hessian sums its <= 2 (corner: F) factors in
-// ascending factor order, so the result does not depend on scheduling.  himu is dense n x n (entries off the band stay 0).
+// ascending factor order, so the result does not depend on scheduling.  himu is COMPACT (li_hb_* below): the 3W-2 state
+// blocks, then the gravity border and corner — 7.2k doubles at W = 10 instead of the 23k of the dense matrix, because
+// the solve kernel pays ~2 us per batch of loads for data another kernel wrote.
 __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiDev *__restrict__ li, const double *__restrict__ imu, double *__restrict__ himu,
                                                 double *__restrict__ gimu) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
         if (b == a) { if (a >= 1) acc += jtj(a - 1, 15 + r, 15 + c); if (a <= W - 2) acc += jtj(a, r, c); }
         else if (b == a + 1) acc = jtj(a, r, 15 + c);
         else acc = jtj(b, 15 + r, c);
-        himu[(size_t)(15 * a + r) * n + 15 * b + c] = acc;
+        himu[li_hb_pair(a, b) + 15 * r + c] = acc;
       }
   }
   if (grav) {                                                // gravity border VM:788-795 and the 3 x 3 corner
@@ -92,14 +107,14 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
       double u1 = 0, u2 = 0;
       if (a >= 1) { u1 += jtj(a - 1, 15 + r, 30 + k); u2 += jtj(a - 1, 30 + k, 15 + r); }
       if (a <= W - 2) { u1 += jtj(a, r, 30 + k); u2 += jtj(a, 30 + k, r); }
-      himu[(size_t)R * n + n - 3 + k] = u1;
-      himu[(size_t)(n - 3 + k) * n + R] = u2;
+      himu[li_hb_ne1(W) + R * 3 + k] = u1;
+      himu[li_hb_ne1(W) + 45 * W + k * 15 * W + R] = u2;
     }
     if (tid < 9) {
       const int r = tid / 3, k = tid - 3 * r;
       double acc = 0;
       for (int f = 0; f < F; f++) acc += jtj(f, 30 + r, 30 + k);
-      himu[(size_t)(n - 3 + r) * n + n - 3 + k] = acc;
+      himu[li_hb_ne1(W) + 90 * W + 3 * r + k] = acc;
     }
   }
   if (tid < n) {                                             // gradient: gg_f(lr) = sum_k joc_f[k][lr] cr_f[k]
@@ -123,13 +138,32 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
   if (tid == 0) { double q = 0; for (int f = 0; f < F; f++) q += qf[f]; li->rimu[0] = q; }
 }
 
-// lower triangle of the assembled Hessian (VM:565-578 / 803-814), before the gauge: imu_coef * IMU part + lidar 6-blocks
+// lower triangle of the assembled Hessian (VM:565-578 / 803-814), before the gauge: imu_coef * IMU part + lidar 6-blocks.
+// Branch-free (every load is issued unconditionally on a clamped index and selected afterwards) so that the 28 gathers a
+// lane performs while the system is dealt to the accumulator tiles overlap instead of serialising behind branches.
 template <int W>
 __device__ __forceinline__ double li_hfull(const double *__restrict__ himu, const double *__restrict__ src, double coef, int n, int r, int c) {
-  double v = coef * himu[(size_t)r * n + c];
-  if (r < 15 * W && c < 15 * W) { const int a = r / 15, lr = r - 15 * a, b = c / 15, lc = c - 15 * b; if (lr < 6 && lc < 6) v += tl_fetch<W>(src, 6 * a + lr, 6 * b + lc); }
-  return v;
+  using C = HessCfg2<W>;
+  const double vi = himu[(size_t)r * n + c];
+  const int a = r / 15, lr = r - 15 * a, b = c / 15, lc = c - 15 * b;
+  const bool lid = (r < 15 * W) && (c < 15 * W) && (lr < 6) && (lc < 6);
+  int row = lid ? 6 * a + lr : 0, col = lid ? 6 * b + lc : 0;
+  if (row > col) { const int t = row; row = col; col = t; }
+  const int ta = row >> 4, tb = col >> 4;
+  const int ut = ta * C::NT16 - ta * (ta - 1) / 2 + (tb - ta);
+  const int rt = row & 15, ct = col & 15;
+  const double v1 = src[ut * 256 + (rt >> 2) * 64 + (rt & 3) * 16 + ct];
+  const int fr = row / 6;
+  const bool dg = (col / 6 == fr);
+  const int aa = row - 6 * fr, bb = dg ? col - 6 * fr : aa;
+  int idx;
+  if (bb < 3) idx = aa * 3 - aa * (aa - 1) / 2 + (bb - aa);
+  else if (aa < 3) idx = 6 + 3 * aa + (bb - 3);
+  else { const int a2 = aa - 3, b2 = bb - 3; idx = 15 + a2 * 3 - a2 * (a2 - 1) / 2 + (b2 - a2); }
+  const double v2 = src[C::EB + 21 * fr + idx];
+  return coef * vi + (lid ? v1 + (dg ? v2 : 0.0) : 0.0);
 }
+
 // ------------------------------------------------------------------------------------------------
 // Blocked LDL^T of a symmetric NP x NP system (NP a multiple of 16) by ONE workgroup, trailing matrix resident in MFMA
 // accumulators.  Pivoting is static (the caller passes the matrix already permuted), which is what Eigen's LDLT amounts
@@ -153,7 +187,7 @@ struct LdltCfg {
 };
 
 template <int NP, int NT, typename F>
-__device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__restrict__ Tp, double *__restrict__ P, int rhs_row, F elem) {
+__device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__restrict__ Tp, double *__restrict__ P, int rhs_row, F elem, long long *stamps = nullptr) {
   using C = LdltCfg<NP>;
   constexpr int NW = NT / 64, TPW = (C::NTILES + NW - 1) / NW, LS = C::LS;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, lr = l >> 4, lc = l & 15;
@@ -174,10 +208,12 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
         for (int r = 0; r < 4; r++) P[(16 * tti[u] + lr + 4 * r) * 8 + lc] = acc[u][r];
     }
   }
+  if (stamps && tid == 0) stamps[2] = clock64();
   for (int kb = 0; kb < C::NBLK; kb++) {
     const int k0 = 8 * kb;
     double *Lk = Lst + C::lst_off(kb);
     __syncthreads();
+    if (stamps && tid == 0 && kb < 20) stamps[8 + 2 * kb] = clock64();
     if (tid < NP && tid >= k0) {
       const int i = tid, ib = i - k0;
       double D[8][8], dd[8], dinv[8], x[8], tm[8];
@@ -223,16 +259,23 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
       }
     }
     __syncthreads();
+    if (stamps && tid == 0 && kb < 20) stamps[9 + 2 * kb] = clock64();
     const int kn = k0 + 8;
     if (kn >= NP) break;
     const int tjn = kn >> 4, cb0 = kn & 15;
+    // operands of every live tile first (unconditional loads on clamped rows: they overlap), then the MFMAs
+    double la0[TPW], la1[TPW], tb0[TPW], tb1[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; u++) {
-      const int t = w + NW * u;
-      if (t < C::NTILES && ttj[u] >= tjn) {    // wave-uniform
-        const double *la = Lk + (16 * tti[u] + lc - k0) * LS + lr, *tb = Tp + (16 * ttj[u] + lc) * LS + lr;
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[0], tb[0], acc[u], 0, 0, 0);
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[4], tb[4], acc[u], 0, 0, 0);
+      const bool act = (w + NW * u < C::NTILES) && (ttj[u] >= tjn);
+      const double *la = Lk + (act ? (16 * tti[u] + lc - k0) : 0) * LS + lr, *tb = Tp + (act ? (16 * ttj[u] + lc) : k0) * LS + lr;
+      la0[u] = la[0]; la1[u] = la[4]; tb0[u] = tb[0]; tb1[u] = tb[4];
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; u++) {
+      if ((w + NW * u < C::NTILES) && (ttj[u] >= tjn)) {    // wave-uniform
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la0[u], tb0[u], acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la1[u], tb1[u], acc[u], 0, 0, 0);
         if (ttj[u] == tjn && lc >= cb0 && lc < cb0 + 8)
 #pragma unroll
           for (int r = 0; r < 4; r++) P[(16 * tti[u] + lr + 4 * r) * 8 + (lc - cb0)] = acc[u][r];
@@ -251,16 +294,35 @@ __device__ __forceinline__ double ldlt_backsub(const double *__restrict__ Lst, d
   double x = (tid < n) ? xs[tid] : 0.0;
   for (int b = nblk - 1; b >= 0; b--) {
     const int hiR = (64 * b + 63 < n - 1) ? 64 * b + 63 : n - 1;
+    // L[j][tid] for fixed tid is linear in j (row stride LS inside one column block): step a pointer, load 8 ahead
+    const double *col = Lst + C::lst_off((tid < n ? tid : 0) >> 3) + (0 - ((tid < n ? tid : 0) & ~7)) * C::LS + ((tid < n ? tid : 0) & 7);   // &L[0][tid]
     if (wv == b) {
-      for (int j = hiR; j > 64 * b; j--) {
+      int j = hiR;
+      for (; j - 7 > 64 * b; j -= 8) {
+        double lv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) lv[q] = (tid < j - q) ? col[(j - q) * C::LS] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const double xj = readlane_f64(x, j - q - 64 * b); x -= lv[q] * xj; }
+      }
+      for (; j > 64 * b; j--) {
         const double xj = readlane_f64(x, j - 64 * b);
-        if (tid < j && tid < n) x -= Lst[C::lat(j, tid)] * xj;
+        if (tid < j && tid < n) x -= col[j * C::LS] * xj;
       }
       if (tid < n) xs[tid] = x;
     }
     __syncthreads();
-    if (wv < b && tid < n)
-      for (int j = 64 * b; j <= hiR; j++) x -= Lst[C::lat(j, tid)] * xs[j];
+    if (wv < b && tid < n) {
+      int j = 64 * b;
+      for (; j + 7 <= hiR; j += 8) {
+        double lv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) lv[q] = col[(j + q) * C::LS];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x -= lv[q] * xs[j + q];
+      }
+      for (; j <= hiR; j++) x -= col[j * C::LS] * xs[j];
+    }
   }
   return x;
 }
@@ -268,7 +330,8 @@ __device__ __forceinline__ double ldlt_backsub(const double *__restrict__ Lst, d
 // (H + u D) dxi = -g for the 15W(+3) system in Eigen-LDLT pivot order, then the retraction of VM:661-671 / 921-934.
 template <int W, int NT>
 __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const double *__restrict__ red, double *__restrict__ raw, int copy_raw,
-                                                 const double *__restrict__ himu, const double *__restrict__ gimu, double *__restrict__ imu) {
+                                                 const double *__restrict__ himu, const double *__restrict__ gimu, double *__restrict__ imu,
+                                                 int n, int gauge, int grav, double coef) {
   using C2 = HessCfg2<W>;
   constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
   using LC = LdltCfg<NP>;
@@ -277,46 +340,129 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   double *hd = P + NP * 8, *gs = hd + NMAX, *dsh = gs + NMAX, *xs = dsh + NMAX, *dxs = xs + NP, *red8 = dxs + NMAX;
   int *ord = (int *)(red8 + 32);
   const int tid = threadIdx.x;
-  if (s->stop) return;
-  const int n = li->n, gauge = li->gauge, calc = s->is_calc_hess, iter0 = s->iter, grav = li->gravity;
-  const double u = s->u, coef = li->imu_coef;
+  // Everything this kernel reads was written by OTHER kernels, in general on another XCD: each dependent trip to memory
+  // costs ~2 us (measured 5k cycles).  So the sizes are kernel arguments and every load the prologue needs — LM flags, the
+  // IMU Hessian, the lidar tiles — is issued up front, before the first branch, and consumed afterwards.
+  const long long t_begin = clock64();
+  // lower part of the compact IMU Hessian: blocks (a, a) and (a, a - 1), then the gravity rows and corner
+  constexpr int NLB = (2 * W - 1) * 225, NLOW = NLB + 45 * W + 9, QH = (NLOW + NT - 1) / NT, NL = 36 * W * W, QL = (NL + NT - 1) / NT;
+  const int nlow = NLB + (grav ? 45 * W + 9 : 0);
+  double hv[QH], lv[QL];
+#pragma unroll
+  for (int q = 0; q < QH; q++) {
+    const int e = tid + NT * q, ec = e < nlow ? e : 0;
+    int idx;
+    if (ec < NLB) { const int blk = ec / 225, a = (blk + 1) >> 1, b = a - (blk & 1); idx = li_hb_pair(a, b) + (ec - 225 * blk); }
+    else idx = li_hb_ne1(W) + 45 * W + (ec - NLB);                  // (g row k, C) rows then the corner, contiguous
+    hv[q] = himu[idx];
+  }
+  if (!copy_raw) {
+#pragma unroll
+    for (int q = 0; q < QL; q++) {
+      const int e = tid + NT * q, ec = e < NL ? e : NL - 1;
+      const int row = ec / (6 * W), col = ec - row * (6 * W);
+      lv[q] = tl_fetch<W>(red, row, col);
+    }
+  }
+  double gimu_v = 0.0, glid_v = 0.0;
+  if (tid < n) {
+    gimu_v = gimu[tid];
+    if (!copy_raw && tid < 15 * W) { const int a = tid / 15, lr = tid - 15 * a; glid_v = (lr < 6) ? red[C2::GB + 6 * a + lr] : 0.0; }
+  }
+  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
+  const double u = s->u, rimu0 = li->rimu[0], rlid0 = copy_raw ? 0.0 : red[C2::RB];
+  if (stop) return;
+  if ((dbg & 16) && tid == 0) s->stamps[0] = t_begin;
   const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
-  if (copy_raw && calc)
-    for (int t = tid; t < C2::NOUT2; t += NT) raw[t] = src[t];
-  if (tid == 0 && calc) { const double r = coef * 0.5 * li->rimu[0] + src[C2::RB]; s->r1 = r; if (iter0 == 0) s->resis_first = r; }
+  if (copy_raw) {                                  // multi-rank: the valid copy depends on is_calc_hess, so these loads come second
+    if (calc)
+      for (int t = tid; t < C2::NOUT2; t += NT) raw[t] = src[t];
+#pragma unroll
+    for (int q = 0; q < QL; q++) {
+      const int e = tid + NT * q, ec = e < NL ? e : NL - 1;
+      const int row = ec / (6 * W), col = ec - row * (6 * W);
+      lv[q] = tl_fetch<W>(src, row, col);
+    }
+    if (tid < 15 * W) { const int a = tid / 15, lr = tid - 15 * a; glid_v = (lr < 6) ? src[C2::GB + 6 * a + lr] : 0.0; }
+  }
+  if (tid == 0 && calc) { const double r = coef * 0.5 * rimu0 + (copy_raw ? src[C2::RB] : rlid0); s->r1 = r; if (iter0 == 0) s->resis_first = r; }
+  // the assembled lower triangle (VM:565-578) is staged in LDS (the region of L is free until the first panel); the
+  // permuted gather into the accumulator tiles then never leaves the CU
+  double *stage = Lst;
+  for (int e = tid; e < n * (n + 1) / 2; e += NT) stage[e] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < QH; q++) {
+    const int e = tid + NT * q;
+    if (e < nlow) {
+      int R, Cc;
+      if (e < NLB) { const int blk = e / 225, rc = e - 225 * blk, a = (blk + 1) >> 1, b = a - (blk & 1); R = 15 * a + rc / 15; Cc = 15 * b + rc % 15; }
+      else if (e < NLB + 45 * W) { const int q2 = e - NLB, k = q2 / (15 * W); R = 15 * W + k; Cc = q2 - k * 15 * W; }
+      else { const int q2 = e - NLB - 45 * W; R = 15 * W + q2 / 3; Cc = 15 * W + q2 % 3; }
+      if (Cc <= R) stage[R * (R + 1) / 2 + Cc] = coef * hv[q];
+    }
+  }
+  __syncthreads();
+  if ((dbg & 16) && tid == 0) s->stamps[50] = clock64();
+#pragma unroll
+  for (int q = 0; q < QL; q++) {                    // lidar 6-blocks (hess_plus VM:509-517)
+    const int e = tid + NT * q;
+    const int row = e / (6 * W), col = e - row * (6 * W);
+    if (e < NL && col <= row) {
+      const int R = 15 * (row / 6) + row % 6, Cc = 15 * (col / 6) + col % 6;
+      stage[R * (R + 1) / 2 + Cc] += lv[q];
+    }
+  }
+  __syncthreads();
+  if ((dbg & 16) && tid == 0) s->stamps[51] = clock64();
   if (tid < n) {
     double h = 1.0, g = 0.0;
     if (tid >= gauge) {
-      h = li_hfull<W>(himu, src, coef, n, tid, tid);
-      g = coef * gimu[tid];
-      if (tid < 15 * W) { const int a = tid / 15, lr = tid - 15 * a; if (lr < 6) g += src[C2::GB + 6 * a + lr]; }
+      h = stage[tid * (tid + 1) / 2 + tid];
+      g = coef * gimu_v + glid_v;
     }
     hd[tid] = h; gs[tid] = g; dsh[tid] = fabs(h + u * h);
   }
   __syncthreads();
-  if (tid < n) {
-    const double me = dsh[tid];
-    int rank = 0;
-    for (int j = 0; j < n; j++) { const double o = dsh[j]; rank += (o > me || (o == me && j < tid)) ? 1 : 0; }
-    ord[rank] = tid;
+  if ((dbg & 16) && tid == 0) s->stamps[52] = clock64();
+  if (tid < n) ord[tid] = 0;                       // rank of row i = #{j : |d_j| > |d_i| or (equal and j < i)}, 3 threads per row
+  __syncthreads();
+  {
+    const int i = tid % NMAX, part = tid / NMAX, parts = NT / NMAX;
+    if (i < n && part < parts) {
+      const double me = dsh[i];
+      const int j0 = part * ((n + parts - 1) / parts), j1 = (j0 + (n + parts - 1) / parts < n) ? j0 + (n + parts - 1) / parts : n;
+      int cnt = 0;
+#pragma unroll 8
+      for (int j = j0; j < j1; j++) { const double o = dsh[j]; cnt += (o > me || (o == me && j < i)) ? 1 : 0; }
+      atomicAdd(&ord[i], cnt);
+    }
   }
+  __syncthreads();
+  int my_rank = (tid < n) ? ord[tid] : 0;
+  __syncthreads();
+  if (tid < n) ord[my_rank] = tid;
   __syncthreads();
   // element (i, j) of the padded system: P (H + u D) P^T lower triangle, row n = -g, identity on the padding
   auto elem = [&](int i, int j) -> double {
-    if (j >= n) return (i == j) ? 1.0 : 0.0;
-    if (i > n || i < j) return 0.0;
-    const int pj = ord[j];
-    if (i == n) return -gs[pj];
-    const int pi = ord[i];
+    const int jc = j < n ? j : n - 1, ic = i < n ? i : n - 1;
+    const int pj = ord[jc], pi = ord[ic];
     const int rr = pi > pj ? pi : pj, cc = pi > pj ? pj : pi;
-    double a = (rr < gauge || cc < gauge) ? ((rr == cc) ? 1.0 : 0.0) : li_hfull<W>(himu, src, coef, n, rr, cc);
-    if (i == j) a += u * a;
-    return a;
+    double a = stage[rr * (rr + 1) / 2 + cc];
+    a = (rr < gauge || cc < gauge) ? ((rr == cc) ? 1.0 : 0.0) : a;
+    a = (i == j) ? a + u * a : a;
+    a = (i == n) ? -gs[pj] : a;
+    a = (i > n || i < j) ? 0.0 : a;
+    return (j >= n) ? ((i == j) ? 1.0 : 0.0) : a;
   };
-  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem);
+  long long *stamps = ((dbg & 16) != 0) ? s->stamps : nullptr;
+  if (stamps && tid == 0) stamps[1] = clock64();
+  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem, stamps);
+  if (stamps && tid == 0) stamps[3] = clock64();
   if (tid < n) xs[tid] = Lst[LC::lat(n, tid)];                                  // z = D^-1 L^-1 P (-g)
   __syncthreads();
   const double x = ldlt_backsub<NP>(Lst, xs, n);
+  if (stamps && tid == 0) stamps[4] = clock64();
   if (tid < n) dxs[ord[tid]] = x;
   __syncthreads();
   // retraction VM:661-671 / 921-934 and the bias increments of IMU_PRE::update_state (PI:296-303)
@@ -347,6 +493,7 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   if ((tid & 63) == 0) red8[tid >> 6] = q;
   __syncthreads();
   if (tid == 0) { double t = 0; for (int w2 = 0; w2 < NT / 64; w2++) t += red8[w2]; s->q1 = 0.5 * t; }
+  if (stamps && tid == 0) stamps[5] = clock64();
 }
 
 // only_residual's IMU part at the trial states (VM:605-607 / 851-854) + the accept / reject bookkeeping of VM:675-706.

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <chrono>
 #include <deque>
 
 using namespace vba;
@@ -83,6 +84,8 @@ struct vba_ctx {
   // device-resident LI-BA (vba_kernels_li.hpp)
   LiDev *d_li = nullptr;
   double *d_imu = nullptr, *d_himu = nullptr, *d_gimu = nullptr;
+  hipStream_t li_stream = nullptr;      // IMU factors run beside the lidar Hessian pass
+  hipEvent_t li_fork = nullptr, li_join = nullptr;
 
   MapStore map;
   GbaStore gba;
@@ -424,6 +427,9 @@ void vba_destroy(vba_ctx *c) {
   c->gba.free_all();
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
+  if (c->li_fork) hipEventDestroy(c->li_fork);
+  if (c->li_join) hipEventDestroy(c->li_join);
+  if (c->li_stream) hipStreamDestroy(c->li_stream);
   if (c->d_imu) hipFree(c->d_imu);
   if (c->d_himu) hipFree(c->d_himu);
   if (c->d_gimu) hipFree(c->d_gimu);
@@ -676,18 +682,22 @@ int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
 // ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity on the device
 extern "C++" {
 template <int W, int NT = 512>
-static void launch_li_solve(vba_ctx *c, int copy_raw) {
+static void launch_li_solve(vba_ctx *c, int copy_raw, int n, int gauge, int grav) {
   constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
   constexpr size_t lds = ((size_t)LdltCfg<NP>::DOUBLES + 4 * NMAX + NP + 32) * 8 + (size_t)NMAX * 4 + 64;
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  hipLaunchKernelGGL((k_li_solve<W, NT>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu);
+  hipLaunchKernelGGL((k_li_solve<W, NT>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
+                     c->opt.imu_coef);
 }
 }  // extern "C++"
 
 static bool li_device_supported(int W) { return W == 2 || W == 3 || W == 4 || W == 5 || W == 6 || W == 8 || W == 10; }
 
 static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
+  static const bool want_times = getenv("VBA_LI_TIMES") != nullptr;   // diagnostic: host-side phases of one call
+  const auto t_0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   const int W = c->opt.win_size, V = c->nvox, DIM = VBA_DIM, F = W - 1;
   const int n = W * DIM + (gravity ? 3 : 0), nb = gravity ? 33 : 30, n6 = 6 * W;
   if (!gravity) max_iter = 3;                                         // VM:643
@@ -696,6 +706,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     HIPCHK(c, hipMalloc((void **)&c->d_imu, (size_t)LI_MAX_W * 304 * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_himu, (size_t)LI_MAX_N * LI_MAX_N * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_gimu, (size_t)LI_MAX_N * sizeof(double)));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->li_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->li_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->li_join, hipEventDisableTiming));
   }
   // upload: LM state (poses view), the IMU extras, the factors with cov^-1 in place of cov
   std::vector<double> poses((size_t)W * 12);
@@ -714,7 +727,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   for (int f = 0; f < F; f++) vbh::inverse_pplu(imus + 304 * (size_t)f + 79, fimg.data() + 304 * (size_t)f + 79, 15);   // PI:166 / 244
   HIPCHK(c, hipMemcpyAsync(c->d_li, &h, sizeof(LiDev), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_imu, fimg.data(), fimg.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_himu, 0, (size_t)n * n * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_himu, 0, (size_t)li_hb_size(W, 1) * sizeof(double), c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_gimu, 0, (size_t)n * sizeof(double), c->stream));
   char *base = reinterpret_cast<char *>(c->d_lm);
   const double *x_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, x));
@@ -723,24 +736,28 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
   const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
   const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16) * sizeof(double);
+  const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
+    // the IMU factors (one workgroup) run on a side stream under the lidar Hessian pass; both only read the LM state
+    HIPCHK(c, hipEventRecord(c->li_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->li_stream, c->li_fork, 0));
+    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, c->li_stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
+    HIPCHK(c, hipEventRecord(c->li_join, c->li_stream));
     st = hessian_pass(c, x_dev, run_hess, 0, V);                      // lidar part of divide_thread (+ all-reduce)
     if (st) { c->lm.active = false; return st; }
-    TimedSpan s0{}, s1{};
-    span_begin(c, "imu", s0);
-    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
-    span_end(c, "imu", s0);
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->li_join, 0));
+    TimedSpan s1{};
     span_begin(c, "solve", s1);
     switch (W) {
-      case 2: launch_li_solve<2>(c, copy_raw); break;
-      case 3: launch_li_solve<3>(c, copy_raw); break;
-      case 4: launch_li_solve<4>(c, copy_raw); break;
-      case 5: launch_li_solve<5>(c, copy_raw); break;
-      case 6: launch_li_solve<6>(c, copy_raw); break;
-      case 8: launch_li_solve<8>(c, copy_raw); break;
+      case 2: launch_li_solve<2>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 3: launch_li_solve<3>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 4: launch_li_solve<4>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 5: launch_li_solve<5>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 6: launch_li_solve<6>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 8: launch_li_solve<8>(c, copy_raw, n, h.gauge, h.gravity); break;
       case 10: {
         static const int nt = getenv("VBA_LI_NT") ? atoi(getenv("VBA_LI_NT")) : 512;      // tuning knob
-        if (nt == 256) launch_li_solve<10, 256>(c, copy_raw); else if (nt == 1024) launch_li_solve<10, 1024>(c, copy_raw); else launch_li_solve<10, 512>(c, copy_raw);
+        if (nt == 256) launch_li_solve<10, 256>(c, copy_raw, n, h.gauge, h.gravity); else if (nt == 1024) launch_li_solve<10, 1024>(c, copy_raw, n, h.gauge, h.gravity); else launch_li_solve<10, 512>(c, copy_raw, n, h.gauge, h.gravity);
         break;
       }
       default: c->lm.active = false; return VBA_ERR_UNSUPPORTED_WINDOW;
@@ -760,6 +777,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     }
     HIPCHK(c, hipGetLastError());
   }
+  const double t_enq = since(t_0);
+  if (want_times) { hipStreamSynchronize(c->stream); }
+  const double t_gpu = since(t_0);
   // download: accepted state, the factors' bias increments, trace, and (on request) *hess = Hess before gauge fixing
   std::vector<double> himu;
   st = ensure_pin(c, 65536 + (size_t)n6 * n6 + 1024);
@@ -768,7 +788,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   HIPCHK(c, hipMemcpyAsync(&h, c->d_li, sizeof(LiDev), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(fimg.data(), c->d_imu, fimg.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (hess) {
-    himu.resize((size_t)n * n);
+    himu.resize((size_t)li_hb_size(W, gravity));
     st = tiles_to_full(c, copy_raw ? c->d_raw : c->d_out);
     if (st) return st;
     HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, c->d_full, (size_t)n6 * n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -785,7 +805,8 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   for (int f = 0; f < F; f++) std::memcpy(imus + 304 * (size_t)f + 67, fimg.data() + 304 * (size_t)f + 67, 12 * sizeof(double));   // dbg, dba, dbg_buf, dba_buf
   if (hess) {
     const double *lid = c->h_pin + 32768;
-    for (size_t t = 0; t < himu.size(); t++) hess[t] = c->opt.imu_coef * himu[t];                                                   // VM:565
+    for (int r = 0; r < n; r++)
+      for (int k = 0; k < n; k++) hess[(size_t)r * n + k] = c->opt.imu_coef * li_hb_get(himu.data(), W, n, r, k);                     // VM:565
     for (int i = 0; i < W; i++)
       for (int j = 0; j < W; j++)
         for (int r = 0; r < 6; r++)
@@ -793,6 +814,14 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   }
   if (gravity && resis2) { resis2[0] = hl->resis_first; resis2[1] = hl->r2; }
   c->trace.assign(hl->trace, hl->trace + 5 * hl->n_trace);
+  if (want_times && (hl->pad & 16)) {
+    fprintf(stderr, "[k_li_solve prologue] stage imu %lld | stage lidar %lld | diag+g %lld | rank %lld\n", hl->stamps[50] - hl->stamps[0], hl->stamps[51] - hl->stamps[50], hl->stamps[52] - hl->stamps[51], hl->stamps[1] - hl->stamps[52]);
+    fprintf(stderr, "[k_li_solve cycles] prologue %lld | tile load %lld | factorisation %lld | backsub %lld | epilogue %lld | panels:", hl->stamps[1] - hl->stamps[0],
+            hl->stamps[2] - hl->stamps[1], hl->stamps[3] - hl->stamps[2], hl->stamps[4] - hl->stamps[3], hl->stamps[5] - hl->stamps[4]);
+    for (int kb = 0; kb < 20; kb++) fprintf(stderr, " %lld+%lld", hl->stamps[9 + 2 * kb] - hl->stamps[8 + 2 * kb], kb < 19 ? hl->stamps[10 + 2 * kb] - hl->stamps[9 + 2 * kb] : 0LL);
+    fprintf(stderr, "\n");
+  }
+  if (want_times) fprintf(stderr, "[li_ba_device] upload %.1f us | enqueue %.1f | gpu drained at %.1f | total %.1f\n", t_up, t_enq - t_up, t_gpu, since(t_0));
   return VBA_OK;
 }
 
