@@ -5,6 +5,7 @@
 // kernels test on entry.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "vba_ldlt.hpp"
 
 namespace vba {
 
@@ -31,12 +32,6 @@ __device__ __forceinline__ void so3_exp_dev(const double *w, double *R) {   // t
   }
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane);
-  hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
 
 // `red` = the reduced [H | g | r] of the last Hessian pass.  It is never modified here: the gauge (first 6 rows/cols ->
 // identity, JacT.head(6) = 0, VM:452-455) and the damping u*diag are applied while the system is loaded, so a rejected
@@ -276,6 +271,119 @@ __global__ __launch_bounds__(128) void k_lm_solve_g(LmDev *s, const double *__re
     for (int j = 0; j < n; j++) q += y[j];
     s->q1 = 0.5 * q;
   }
+}
+
+// Blocked variant (vba_ldlt.hpp) for every supported window (n = 6W <= 96): trailing matrix in MFMA accumulators, panels
+// of 8 columns, two barriers per panel.  Everything the kernel reads was written by other kernels (in general on another
+// XCD, ~2 us per dependent trip), so the whole reduced system is requested up front and staged in LDS before the first branch.
+template <int W>
+__global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw) {
+  using C2 = HessCfg2<W>;
+  constexpr int n = 6 * W, NT = 256, NP = ((n + 1 + 15) / 16) * 16;
+  using LC = LdltCfg<NP>;
+  constexpr int STG = n * (n + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double lds[LC::DOUBLES > STG ? LC::DOUBLES : STG];
+  __shared__ double hd[n], gs[n], dsh[n], xs[NP], dxs[n], red8[8];
+  __shared__ int ord[n];
+  double *Lst = lds, *Tp = Lst + LC::LTOT, *P = Tp + NP * LC::LS, *stage = lds;
+  const int tid = threadIdx.x;
+  constexpr int NL = n * n, QL = (NL + NT - 1) / NT;
+  double lv[QL];
+  if (!copy_raw) {
+#pragma unroll
+    for (int q = 0; q < QL; q++) {
+      const int e = tid + NT * q, ec = e < NL ? e : NL - 1;
+      const int row = ec / n, col = ec - row * n;
+      lv[q] = tl_fetch<W>(red, row, col);
+    }
+  }
+  double g_v = (!copy_raw && tid < n) ? red[C2::GB + tid] : 0.0;
+  double xr[12];
+  if (tid < W)
+#pragma unroll
+    for (int k = 0; k < 12; k++) xr[k] = s->x[12 * tid + k];
+  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter;
+  const double u = s->u, r_v = copy_raw ? 0.0 : red[C2::RB];
+  if (stop) return;
+  const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
+  if (copy_raw) {
+    if (calc)
+      for (int t = tid; t < C2::NOUT2; t += NT) raw[t] = src[t];
+#pragma unroll
+    for (int q = 0; q < QL; q++) {
+      const int e = tid + NT * q, ec = e < NL ? e : NL - 1;
+      const int row = ec / n, col = ec - row * n;
+      lv[q] = tl_fetch<W>(src, row, col);
+    }
+    if (tid < n) g_v = src[C2::GB + tid];
+  }
+  if (tid == 0 && calc) { const double r = copy_raw ? src[C2::RB] : r_v; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
+#pragma unroll
+  for (int q = 0; q < QL; q++) {
+    const int e = tid + NT * q;
+    const int row = e / n, col = e - row * n;
+    if (e < NL && col <= row) stage[row * (row + 1) / 2 + col] = lv[q];
+  }
+  __syncthreads();
+  if (tid < n) {
+    const double h = tid < 6 ? 1.0 : stage[tid * (tid + 1) / 2 + tid];                                  // gauge VM:452-455
+    hd[tid] = h; gs[tid] = tid < 6 ? 0.0 : g_v;
+    dsh[tid] = fabs(h + u * h);
+    ord[tid] = 0;
+  }
+  __syncthreads();
+  {
+    constexpr int parts = NT / n;
+    const int i = tid % n, part = tid / n;
+    if (part < parts) {
+      const double me = dsh[i];
+      constexpr int seg = (n + parts - 1) / parts;
+      const int j0 = part * seg, j1 = (j0 + seg < n) ? j0 + seg : n;
+      int cnt = 0;
+#pragma unroll 8
+      for (int j = j0; j < j1; j++) { const double o = dsh[j]; cnt += (o > me || (o == me && j < i)) ? 1 : 0; }
+      atomicAdd(&ord[i], cnt);
+    }
+  }
+  __syncthreads();
+  const int my_rank = (tid < n) ? ord[tid] : 0;
+  __syncthreads();
+  if (tid < n) ord[my_rank] = tid;
+  __syncthreads();
+  auto elem = [&](int i, int j) -> double {        // P (Hess + u D) P^T lower triangle, row n = -g, identity on the padding
+    const int jc = j < n ? j : n - 1, ic = i < n ? i : n - 1;
+    const int pj = ord[jc], pi = ord[ic];
+    const int rr = pi > pj ? pi : pj, cc = pi > pj ? pj : pi;
+    double a = stage[rr * (rr + 1) / 2 + cc];
+    a = (rr < 6 || cc < 6) ? ((rr == cc) ? 1.0 : 0.0) : a;
+    a = (i == j) ? a + u * a : a;
+    a = (i == n) ? -gs[pj] : a;
+    a = (i > n || i < j) ? 0.0 : a;
+    return (j >= n) ? ((i == j) ? 1.0 : 0.0) : a;
+  };
+  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem);
+  if (tid < n) xs[tid] = Lst[LC::lat(n, tid)];
+  __syncthreads();
+  const double x = ldlt_backsub<NP>(Lst, xs, n);
+  if (tid < n) dxs[ord[tid]] = x;
+  __syncthreads();
+  if (tid < W) {                                                                                        // VM:460-464
+    double E[9];
+    so3_exp_dev(dxs + 6 * tid, E);
+    const double *R = xr;
+    double *Rt = s->xt + 12 * tid;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * E[c] + R[3 * r + 1] * E[3 + c] + R[3 * r + 2] * E[6 + c];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dxs[6 * tid + 3 + k];
+  }
+  double q = tid < n ? dxs[tid] * (u * hd[tid] * dxs[tid] - gs[tid]) : 0.0;                              // VM:465
+  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+  if ((tid & 63) == 0) red8[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) s->q1 = 0.5 * (red8[0] + red8[1] + red8[2] + red8[3]);
 }
 
 // Accept / reject bookkeeping of VM:467-494 (one thread).  r2_dev = the reduced residual of the trial poses.

@@ -591,6 +591,18 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   TimedSpan sp{};
   span_begin(c, "solve", sp);
   const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
+  static const bool old_solve = getenv("VBA_SOLVE_OLD") != nullptr;     // diagnostic: the single-wave / unblocked kernels
+  bool launched = false;
+  if (!old_solve) {
+    launched = true;
+    switch (W) {
+#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+      VBA_SM_CASE(2) VBA_SM_CASE(3) VBA_SM_CASE(4) VBA_SM_CASE(5) VBA_SM_CASE(6) VBA_SM_CASE(8) VBA_SM_CASE(10) VBA_SM_CASE(12) VBA_SM_CASE(16)
+#undef VBA_SM_CASE
+      default: launched = false;
+    }
+  }
+  if (!launched)
   switch (W) {
     case 2: hipLaunchKernelGGL(k_lm_solve_w<2>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
     case 3: hipLaunchKernelGGL(k_lm_solve_w<3>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
