@@ -177,8 +177,8 @@ def cold_residual_pass(ctx, torch, poses0, V, occ, W, reps=12):
 
 
 def li_variant(ctx, capi, wl, scans, poses0, reps=15):
-    """LiDAR-inertial optimiser (LI_BA_Optimizer, voxel_map.hpp:504-714) on the same factor store: device K3/K4, IMU factors
-    and the 15W solve on the host."""
+    """LiDAR-inertial optimiser (LI_BA_Optimizer, voxel_map.hpp:504-714) on the same factor store, device resident: K3/K4, the IMU
+    factor kernel, the 150x150 blocked LDL^T and the accept/reject kernel; one call = upload, 3 LM iterations, states + Hessian back."""
     from voxel_slam_amd import synth
     W = wl.win_size
     imu_samples, vel, g = synth.make_imu(wl, gyr_sigma=1e-3, acc_sigma=1e-2)
@@ -196,7 +196,7 @@ def li_variant(ctx, capi, wl, scans, poses0, reps=15):
         n += len(out["trace"])
     dt = time.perf_counter() - t0
     return {"iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n, "iterations": n,
-            "what": "LI_BA_Optimizer::damping_iter, %d IMU factors, 150x150 system" % (W - 1)}
+            "what": "LI_BA_Optimizer::damping_iter, %d IMU factors, 150x150 system; per-call upload/download amortised over its 3 iterations" % (W - 1)}
 
 
 def hba_window(capi, torch, reps=10, cpu=True):

@@ -66,8 +66,7 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
     if (stamps && tid == 0 && kb < 20) stamps[8 + 2 * kb] = clock64();
     if (tid < NP && tid >= k0) {
       const int i = tid, ib = i - k0;
-      double D[8][8], dd[8], dinv[8], x[8], tm[8];
-      bool ok[8];
+      double D[8][8], x[8];
 #pragma unroll
       for (int r = 0; r < 8; r++)
 #pragma unroll
@@ -77,35 +76,33 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
                       x2 = *reinterpret_cast<const double2 *>(P + i * 8 + 4), x3 = *reinterpret_cast<const double2 *>(P + i * 8 + 6);
         x[0] = x0.x; x[1] = x0.y; x[2] = x1.x; x[3] = x1.y; x[4] = x2.x; x[5] = x2.y; x[6] = x3.x; x[7] = x3.y;
       }
+      const bool is_rhs = (i == rhs_row);
 #pragma unroll
-      for (int c = 0; c < 8; c++) {            // right-looking elimination of the diagonal block, identical in every lane
+      for (int c = 0; c < 8; c++) {
+        // pivot c of the diagonal block (identical in every lane) ...
         const double d = D[c][c];
-        ok[c] = fabs(d) > 0.0;
+        const bool ok = fabs(d) > 0.0;
         double inv = __builtin_amdgcn_rcp(d);
         inv = fma(fma(-d, inv, 1.0), inv, inv);
         inv = fma(fma(-d, inv, 1.0), inv, inv);
-        dd[c] = d; dinv[c] = ok[c] ? inv : 0.0;
+        const double dinv = ok ? inv : 0.0;
+        // ... this lane's row, right-looking: l_c is final once columns < c have been applied to x[c]
+        double lv = ok ? x[c] * dinv : x[c];
+        if (is_rhs) lv = (fabs(d) > 2.2250738585072014e-308) ? x[c] * dinv : 0.0;
+        lv = (ib > c) ? lv : 0.0;               // rows of the diagonal block: strictly lower part only
+        const double tmc = lv * d;
+        Lk[ib * LS + c] = lv;
+        Tp[i * LS + c] = -tmc;
 #pragma unroll
-        for (int r = c + 1; r < 8; r++) D[r][c] = ok[c] ? D[r][c] * inv : D[r][c];      // L[r][c]
+        for (int r = c + 1; r < 8; r++) D[r][c] = ok ? D[r][c] * inv : D[r][c];      // L[r][c] of the block
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; c2++) x[c2] -= tmc * D[c2][c];
 #pragma unroll
         for (int r = c + 1; r < 8; r++) {
           const double t = D[r][c] * d;                                                  // T[r][c]
 #pragma unroll
           for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] -= t * D[c2][c];
         }
-      }
-      const bool is_rhs = (i == rhs_row);
-#pragma unroll
-      for (int c = 0; c < 8; c++) {            // this lane's row against the block: l_c = (x_c - sum_m t_m Ld[c][m]) / d_c
-        double sacc = x[c];
-#pragma unroll
-        for (int m = 0; m < c; m++) sacc -= tm[m] * D[c][m];
-        double lv = ok[c] ? sacc * dinv[c] : sacc;
-        if (is_rhs) lv = (fabs(dd[c]) > 2.2250738585072014e-308) ? sacc * dinv[c] : 0.0;
-        lv = (ib > c) ? lv : 0.0;             // rows of the diagonal block: strictly lower part only
-        tm[c] = lv * dd[c];
-        Lk[ib * LS + c] = lv;
-        Tp[i * LS + c] = -tm[c];
       }
     }
     __syncthreads();

@@ -737,8 +737,11 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   std::vector<double> fimg((size_t)F * 304);
   std::memcpy(fimg.data(), imus, fimg.size() * sizeof(double));
   for (int f = 0; f < F; f++) vbh::inverse_pplu(imus + 304 * (size_t)f + 79, fimg.data() + 304 * (size_t)f + 79, 15);   // PI:166 / 244
-  HIPCHK(c, hipMemcpyAsync(c->d_li, &h, sizeof(LiDev), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_imu, fimg.data(), fimg.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  {
+    // (small pageable uploads are staged synchronously by the runtime, so the stack / vector sources may die after this)
+    HIPCHK(c, hipMemcpyAsync(c->d_li, &h, sizeof(LiDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu, fimg.data(), fimg.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
   HIPCHK(c, hipMemsetAsync(c->d_himu, 0, (size_t)li_hb_size(W, 1) * sizeof(double), c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_gimu, 0, (size_t)n * sizeof(double), c->stream));
   char *base = reinterpret_cast<char *>(c->d_lm);
@@ -792,21 +795,25 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const double t_enq = since(t_0);
   if (want_times) { hipStreamSynchronize(c->stream); }
   const double t_gpu = since(t_0);
-  // download: accepted state, the factors' bias increments, trace, and (on request) *hess = Hess before gauge fixing
-  std::vector<double> himu;
-  st = ensure_pin(c, 65536 + (size_t)n6 * n6 + 1024);
+  // download: accepted state, the factors' bias increments, trace, and (on request) *hess = Hess before gauge fixing —
+  // everything lands in ONE pinned block (pageable destinations make every copy a blocking staged transfer)
+  const size_t o_li = 0, o_img = o_li + (sizeof(LiDev) + 7) / 8, o_hb = o_img + fimg.size(), o_lid = o_hb + (size_t)li_hb_size(W, 1),
+               o_end = o_lid + (size_t)n6 * n6;
+  st = ensure_pin(c, o_end + 64);
   if (st) return st;
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&h, c->d_li, sizeof(LiDev), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(fimg.data(), c->d_imu, fimg.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pin + o_li, c->d_li, sizeof(LiDev), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pin + o_img, c->d_imu, fimg.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (hess) {
-    himu.resize((size_t)li_hb_size(W, gravity));
     st = tiles_to_full(c, copy_raw ? c->d_raw : c->d_out);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, c->d_full, (size_t)n6 * n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(himu.data(), c->d_himu, himu.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + o_lid, c->d_full, (size_t)n6 * n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + o_hb, c->d_himu, (size_t)li_hb_size(W, gravity) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(&h, c->h_pin + o_li, sizeof(LiDev));
+  std::memcpy(fimg.data(), c->h_pin + o_img, fimg.size() * sizeof(double));
+  const double *himu_h = c->h_pin + o_hb;
   c->lm.active = false;
   const LmDev *hl = c->h_lm;
   for (int i = 0; i < W; i++) {
@@ -816,9 +823,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   }
   for (int f = 0; f < F; f++) std::memcpy(imus + 304 * (size_t)f + 67, fimg.data() + 304 * (size_t)f + 67, 12 * sizeof(double));   // dbg, dba, dbg_buf, dba_buf
   if (hess) {
-    const double *lid = c->h_pin + 32768;
+    const double *lid = c->h_pin + o_lid;
     for (int r = 0; r < n; r++)
-      for (int k = 0; k < n; k++) hess[(size_t)r * n + k] = c->opt.imu_coef * li_hb_get(himu.data(), W, n, r, k);                     // VM:565
+      for (int k = 0; k < n; k++) hess[(size_t)r * n + k] = c->opt.imu_coef * li_hb_get(himu_h, W, n, r, k);                     // VM:565
     for (int i = 0; i < W; i++)
       for (int j = 0; j < W; j++)
         for (int r = 0; r < 6; r++)
