@@ -273,11 +273,7 @@ def main():
     if world > 1:
         ctx.set_shard(rank, world)        # K1 keeps only the points whose root voxel falls in this rank's bucket range
 
-        def hook(ptr, n, _stream):
-            t = _tensor_from_ptr(torch, ptr, n)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return 0
-        ctx.set_allreduce(hook)
+        ctx.set_torch_allreduce(torch, dist)   # collective issued on the context's stream (RCCL all_reduce, SUM)
 
     # full-window rebuild on the device (voxelslam.cpp:664-703): K1 insert of W scans, K2 recut + factor extraction.
     # The scans are uploaded to HBM once; the timed rebuild passes consume device pointers.

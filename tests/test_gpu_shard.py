@@ -30,37 +30,43 @@ def _worker(rank, world, port, out_dir):
     s = synth.make_scans(wl)
     W = wl.win_size
     poses = synth.poses_flat(s["R0"], s["p0"])
+    imu_samples, vel, g = synth.make_imu(wl, gyr_sigma=1e-3, acc_sigma=1e-2)
+    nm = np.array([0.01] * 3 + [1.0] * 3); nw = np.array([1e-4] * 6)
+    imus = np.stack([capi.imu_preintegrate(t, gy, ac, np.zeros(3), np.zeros(3), nm, nw) for (t, gy, ac) in imu_samples])
+    states = np.zeros((W, 25))
+    for i in range(W):
+        states[i, 0] = 0.1 * i; states[i, 1:10] = s["R0"][i].ravel(); states[i, 10:13] = s["p0"][i]; states[i, 13:16] = vel[i]; states[i, 22:25] = g
 
     def run(shard):
         ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
         if shard:
             ctx.set_shard(rank, world)
-            cache = {}
-
-            def hook(ptr, n, _stream):
-                if (ptr, n) not in cache:
-                    class _Ext:
-                        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
-                    cache[(ptr, n)] = torch.as_tensor(_Ext(), device="cuda")
-                dist.all_reduce(cache[(ptr, n)], op=dist.ReduceOp.SUM)
-                return 0
-            ctx.set_allreduce(hook)
+            ctx.set_torch_allreduce(torch, dist)
         for i in range(W):
             ctx.cut_voxel(i, s["points"][i], poses[i])
         ctx.recut(W, poses, multi=False)
         nv = ctx.size()
         out = ctx.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
-        return nv, out
+        # LiDAR-inertial optimiser on the same sharded store: the IMU factors are replicated on every rank, only the
+        # lidar [H|g|r] and the residual scalar go through the hook
+        ctx.evaluate_only_residual(poses)
+        li = ctx.li_ba_damping_iter(states, imus, gravity=True, max_iter=3)
+        return nv, out, li
 
-    nv_s, sharded = run(True)
+    nv_s, sharded, li_s = run(True)
     cnt = torch.tensor([nv_s]); dist.all_reduce(cnt)
     if rank == 0:
-        nv_f, full = run(False)
+        nv_f, full, li_f = run(False)
         ok = (int(cnt.item()) == nv_f and np.abs(sharded["poses"] - full["poses"]).max() < 1e-8
               and np.allclose(sharded["trace"], full["trace"], rtol=1e-7, atol=1e-12)
-              and np.abs(sharded["hess"] - full["hess"]).max() < 1e-8 * np.abs(full["hess"]).max())
+              and np.abs(sharded["hess"] - full["hess"]).max() < 1e-8 * np.abs(full["hess"]).max()
+              and np.abs(li_s["states"] - li_f["states"]).max() < 1e-8
+              and np.allclose(li_s["trace"], li_f["trace"], rtol=1e-7, atol=1e-12)
+              and np.abs(li_s["hess"] - li_f["hess"]).max() < 1e-8 * np.abs(li_f["hess"]).max())
         open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write(
-            "%d %d %g" % (int(cnt.item()), nv_f, np.abs(sharded["poses"] - full["poses"]).max()))
+            "voxels %d %d | lidar poses %g | LI states %g FULLROW0 %s trace %s vs %s hess %g" % (
+                int(cnt.item()), nv_f, np.abs(sharded["poses"] - full["poses"]).max(), np.abs(li_s["states"] - li_f["states"]).max(), li_f["trace"][0].tolist(),
+                li_s["trace"].tolist(), li_f["trace"].tolist(), np.abs(li_s["hess"] - li_f["hess"]).max() / np.abs(li_f["hess"]).max()))
     dist.barrier()
     dist.destroy_process_group()
 

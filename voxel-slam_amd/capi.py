@@ -368,6 +368,25 @@ class Context:
         self._cb = ALLREDUCE_FN(tramp)
         self._chk(self.lib.vba_set_allreduce(self.h, self._cb, None))
 
+    def set_torch_allreduce(self, torch, dist):
+        """torch.distributed SUM all-reduce (RCCL with backend "nccl", gloo in rehearsals) of the context's device buffers,
+        ORDERED ON THE CONTEXT'S STREAM: the hook is handed the stream the kernels run on, and the collective is issued with
+        that stream current.  (Issuing it on torch's default stream instead leaves it unordered against the context's own
+        non-blocking stream: the sum then races with k_reduce_partials.)"""
+        cache = {}
+
+        def hook(ptr, n, stream):
+            key = (ptr, n)
+            if key not in cache:
+                class _Ext:
+                    __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
+                cache[key] = torch.as_tensor(_Ext(), device="cuda")
+            ext = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.default_stream()
+            with torch.cuda.stream(ext):
+                dist.all_reduce(cache[key], op=dist.ReduceOp.SUM)
+            return 0
+        self.set_allreduce(hook)
+
     def timing_enable(self, on=True):
         self.lib.vba_timing_enable(self.h, C.c_int(int(on)))
 

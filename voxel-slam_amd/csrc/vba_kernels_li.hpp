@@ -222,7 +222,11 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
     }
     if (tid < 15 * W) { const int a = tid / 15, lr = tid - 15 * a; glid_v = (lr < 6) ? src[C2::GB + 6 * a + lr] : 0.0; }
   }
-  if (tid == 0 && calc) { const double r = coef * 0.5 * rimu0 + (copy_raw ? src[C2::RB] : rlid0); s->r1 = r; if (iter0 == 0) s->resis_first = r; }
+  if (tid == 0 && calc) {
+    const double rl = copy_raw ? src[C2::RB] : rlid0, r = coef * 0.5 * rimu0 + rl;
+    s->r1 = r; if (iter0 == 0) s->resis_first = r;
+    if ((dbg & 32) && iter0 < 3) { s->stamps[58 + 2 * iter0] = __double_as_longlong(rimu0); s->stamps[59 + 2 * iter0] = __double_as_longlong(rl); }
+  }
   // the assembled lower triangle (VM:565-578) is staged in LDS (the region of L is free until the first panel); the
   // permuted gather into the accumulator tiles then never leaves the CU
   double *stage = Lst;

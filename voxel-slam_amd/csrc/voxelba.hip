@@ -754,13 +754,17 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
     // the IMU factors (one workgroup) run on a side stream under the lidar Hessian pass; both only read the LM state
-    HIPCHK(c, hipEventRecord(c->li_fork, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->li_stream, c->li_fork, 0));
-    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, c->li_stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
-    HIPCHK(c, hipEventRecord(c->li_join, c->li_stream));
+    static const bool no_side = getenv("VBA_LI_NO_SIDE_STREAM") != nullptr;
+    const bool side = !no_side;
+    if (side) {
+      HIPCHK(c, hipEventRecord(c->li_fork, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->li_stream, c->li_fork, 0));
+    }
+    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, side ? c->li_stream : c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
+    if (side) HIPCHK(c, hipEventRecord(c->li_join, c->li_stream));
     st = hessian_pass(c, x_dev, run_hess, 0, V);                      // lidar part of divide_thread (+ all-reduce)
     if (st) { c->lm.active = false; return st; }
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->li_join, 0));
+    if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->li_join, 0));
     TimedSpan s1{};
     span_begin(c, "solve", s1);
     switch (W) {
@@ -840,6 +844,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     for (int kb = 0; kb < 20; kb++) fprintf(stderr, " %lld+%lld", hl->stamps[9 + 2 * kb] - hl->stamps[8 + 2 * kb], kb < 19 ? hl->stamps[10 + 2 * kb] - hl->stamps[9 + 2 * kb] : 0LL);
     fprintf(stderr, "\n");
   }
+  if (want_times && (hl->pad & 32)) { double v[6]; std::memcpy(v, &hl->stamps[58], sizeof(v)); fprintf(stderr, "[li r1 parts] rank %d: rimu %.10g lidar %.10g | %.10g %.10g | %.10g %.10g\n", c->rank, v[0], v[1], v[2], v[3], v[4], v[5]); }
   if (want_times) fprintf(stderr, "[li_ba_device] upload %.1f us | enqueue %.1f | gpu drained at %.1f | total %.1f\n", t_up, t_enq - t_up, t_gpu, since(t_0));
   return VBA_OK;
 }
