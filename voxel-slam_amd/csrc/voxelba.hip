@@ -78,7 +78,7 @@ struct vba_ctx {
   hipEvent_t lm_up_ev[kLmRing] = {nullptr};
   int lm_up_next = 0;
   double *d_raw = nullptr;        // last valid all-reduced [H|g|r] (multi-rank only; single rank reads d_out in place)
-  struct { bool active = false; int thd_num = 2; } lm;
+  struct { bool active = false; int thd_num = 2; bool have_hess = false; } lm;   // have_hess: [H|g|r] of the next solve is already reduced (multi-rank)
   std::vector<double> trace;
 
   // device-resident LI-BA (vba_kernels_li.hpp)
@@ -562,7 +562,7 @@ int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   { const char *e = getenv("VBA_DEBUG_SOLVE"); h->pad = e ? atoi(e) : 0; }   // timing ablation knob (0 in production)
   HIPCHK(c, hipMemcpyAsync(c->d_lm, h, sizeof(LmDev), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->lm_up_ev[slot], c->stream));
-  c->lm.active = true; c->lm.thd_num = thd_num;
+  c->lm.active = true; c->lm.thd_num = thd_num; c->lm.have_hess = false;
   c->trace.clear();
   return VBA_OK;
 }
@@ -586,11 +586,16 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   const double *xt_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, xt));
   const int *run_hess = reinterpret_cast<const int *>(base + offsetof(LmDev, run_hess));
   const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
-  int st = hessian_pass(c, x_dev, run_hess, 0, V);                    // divide_thread  VM:445 (skipped on device after a reject)
+  // Multi-rank: ONE collective per iteration.  After the residual pass at the trial poses the Hessian pass is run there
+  // too (speculating that the step is accepted) and [H | g | r] is all-reduced once: its r (the sum of the eigenvalues the
+  // residual pass just stored) is the trial residual the accept test needs, and on acceptance H is already the next
+  // iteration's Hessian; on a reject the solve keeps using its saved copy (`raw`), exactly as VM:443 skips divide_thread.
+  const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
+  int st = VBA_OK;
+  if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);   // divide_thread  VM:445 (skipped on device after a reject)
   if (st) return st;
   TimedSpan sp{};
   span_begin(c, "solve", sp);
-  const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
   static const bool old_solve = getenv("VBA_SOLVE_OLD") != nullptr;     // diagnostic: the single-wave / unblocked kernels
   bool launched = false;
   if (!old_solve) {
@@ -621,10 +626,12 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   }
   span_end(c, "solve", sp);
   double *d_r = c->d_scal;
-  if (c->allreduce && c->n_ranks > 1) {
-    st = residual_pass(c, xt_dev, run_res, 0, V, d_r);                // only_residual  VM:467 (+ scalar all-reduce)
+  if (copy_raw) {
+    if (V > 0) launch_residual(c, xt_dev, run_res, 0, V, (V + 63) / 64);   // only_residual VM:467: refreshes the eigen state at the trial poses
+    st = hessian_pass(c, xt_dev, run_res, 0, V);                      // speculative divide_thread there + the one all-reduce
     if (st) return st;
-    hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, d_r, 0, W);
+    c->lm.have_hess = true;
+    hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out + (nout_tl(W) - 1), 0, W);
   } else {
     const int nb = (V + 63) / 64;
     TimedSpan s1{};
@@ -762,7 +769,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     }
     hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, side ? c->li_stream : c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
     if (side) HIPCHK(c, hipEventRecord(c->li_join, c->li_stream));
-    st = hessian_pass(c, x_dev, run_hess, 0, V);                      // lidar part of divide_thread (+ all-reduce)
+    if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);   // lidar part of divide_thread (+ all-reduce)
     if (st) { c->lm.active = false; return st; }
     if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->li_join, 0));
     TimedSpan s1{};
@@ -782,8 +789,14 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
       default: c->lm.active = false; return VBA_ERR_UNSUPPORTED_WINDOW;
     }
     span_end(c, "solve", s1);
-    if (copy_raw || V == 0) {
-      st = residual_pass(c, xt_dev, run_res, 0, V, c->d_scal);        // lidar part of only_residual (+ scalar all-reduce)
+    if (copy_raw) {                                                   // one collective per iteration (see vba_lm_iterate)
+      if (V > 0) launch_residual(c, xt_dev, run_res, 0, V, (V + 63) / 64);
+      st = hessian_pass(c, xt_dev, run_res, 0, V);
+      if (st) { c->lm.active = false; return st; }
+      c->lm.have_hess = true;
+      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_out + (nout_tl(W) - 1), 0);
+    } else if (V == 0) {
+      st = residual_pass(c, xt_dev, run_res, 0, V, c->d_scal);
       if (st) { c->lm.active = false; return st; }
       hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_scal, 0);
     } else {
