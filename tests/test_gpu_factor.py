@@ -196,3 +196,37 @@ def test_li_ba_damping_iter_parity(capi, oracle, synth, gravity, name):
     assert _relerr(a["hess"], b["hess"]) < 1e-7
     if gravity:
         assert np.allclose(a["resis"], b["resis"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("W", [2, 3, 5, 6, 8, 12, 16])
+def test_lm_all_window_sizes(capi, oracle, synth, W):
+    """Every supported window size through the device-resident optimisers (blocked LDL^T: 1..6 accumulator tiles per side,
+    one or two 64-row back-substitution blocks; LI-BA on the device up to W = 10, host solve above)."""
+    import dataclasses
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="room_w%d" % W, win_size=W)
+    s = synth.make_scans(wl)
+    fac = synth.root_factors(s["points"], s["R0"], s["p0"], wl)
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    ctx = _ctx(capi, W, imu_coef=wl.imu_coef); ctx.push_dict(fac)
+    f = oracle.Factor(W); f.push_dict(fac)
+    a = ctx.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
+    b = f.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2, parallel=False)
+    assert a["trace"].shape == b["trace"].shape
+    acc = b["trace"][:, 1] < b["trace"][:, 0]
+    assert np.allclose(a["trace"][acc], b["trace"][acc], rtol=1e-6, atol=1e-12)
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-6
+    # LiDAR-inertial variant on the same store
+    imu_samples, vel, g = synth.make_imu(wl, gyr_sigma=1e-3, acc_sigma=1e-2)
+    nm = np.array([0.01] * 3 + [1.0] * 3); nw = np.array([1e-4] * 6)
+    imus = np.stack([capi.imu_preintegrate(t, gy, ac, np.zeros(3), np.zeros(3), nm, nw) for (t, gy, ac) in imu_samples])
+    states = np.zeros((W, 25))
+    for i in range(W):
+        states[i, 0] = 0.1 * i
+        states[i, 1:10] = s["R0"][i].ravel(); states[i, 10:13] = s["p0"][i]; states[i, 13:16] = vel[i]; states[i, 22:25] = g
+    ctx.evaluate_only_residual(poses); f.evaluate_only_residual(poses)
+    a = ctx.li_ba_damping_iter(states, imus, gravity=True, max_iter=3)
+    b = f.li_ba_damping_iter(states, imus, gravity=True, imu_coef=wl.imu_coef, max_iter=3)
+    assert a["trace"].shape == b["trace"].shape
+    assert np.allclose(a["trace"], b["trace"], rtol=1e-6, atol=1e-10)
+    assert np.abs(a["states"] - b["states"]).max() < 1e-7
+    assert _relerr(a["hess"], b["hess"]) < 1e-7
