@@ -208,6 +208,60 @@ class VoxelMap {
   vba_ctx *c_;
 };
 
+// ---- scan pre-processing and hierarchical global BA (free functions of the reference: tools.hpp / voxelslam.cpp)
+struct XYZ { float x, y, z; };   // the coordinates of a pcl::PointXYZINormal
+
+// down_sampling_voxel(pl_feat, voxel_size) TL:201-238: pl is replaced by the centroids; counts[i] = the `curvature` field
+// after the call, first[i] = index (in the input) of the point whose other fields the reference keeps.
+inline void down_sampling_voxel(Context &ctx, std::vector<XYZ> &pl, double voxel_size, std::vector<int> *counts = nullptr,
+                                std::vector<int> *first = nullptr) {
+  const int n = (int)pl.size();
+  std::vector<double> in((size_t)n * 3), out((size_t)n * 3);
+  std::vector<int> cnt(n), fst(n);
+  for (int i = 0; i < n; i++) { in[3 * i] = pl[i].x; in[3 * i + 1] = pl[i].y; in[3 * i + 2] = pl[i].z; }
+  int m = 0;
+  check(ctx.get(), vba_scan_down_sampling_voxel(ctx.get(), n, in.data(), voxel_size, out.data(), cnt.data(), fst.data(), &m));
+  pl.resize(m);
+  for (int i = 0; i < m; i++) { pl[i].x = (float)out[3 * i]; pl[i].y = (float)out[3 * i + 1]; pl[i].z = (float)out[3 * i + 2]; }
+  cnt.resize(m); fst.resize(m);
+  if (counts) *counts = cnt;
+  if (first) *first = fst;
+}
+
+struct GbaEdge { int i, j; double rot[9], tra[3], v6[6]; };   // the arguments of PGO_Edges::push, LR:247
+
+// The optimisation part of VOXEL_SLAM::HBA_add_edge (VS:2858-2951) for one connected keyframe set: xs in/out,
+// clouds[i] = keyframe i's points in its own frame.  submap (optional) receives the cloud of VS:2954-2989.
+inline std::vector<GbaEdge> HBA_add_edge(Context &ctx, std::vector<IMUST> &xs, const std::vector<std::vector<XYZ>> &clouds, double gba_voxel_size,
+                                         double gba_min_eigen_value, const std::vector<double> &gba_eigen_value_array, int max_iter, int thread_num,
+                                         std::vector<XYZ> *submap = nullptr) {
+  const int W = (int)xs.size();
+  std::vector<int> off(W + 1, 0);
+  for (int i = 0; i < W; i++) off[i + 1] = off[i] + (int)clouds[i].size();
+  std::vector<double> pts((size_t)off[W] * 3), poses = LidarFactor::poses_of(xs), edges((size_t)(W * (W - 1) / 2 + 1) * 20);
+  for (int i = 0; i < W; i++)
+    for (size_t k = 0; k < clouds[i].size(); k++) {
+      double *q = &pts[((size_t)off[i] + k) * 3];
+      q[0] = clouds[i][k].x; q[1] = clouds[i][k].y; q[2] = clouds[i][k].z;
+    }
+  double eig[4] = {0, 0, 0, 0};
+  for (size_t k = 0; k < 4 && k < gba_eigen_value_array.size(); k++) eig[k] = gba_eigen_value_array[k];
+  std::vector<double> cloud(submap ? pts.size() : 0);
+  std::vector<int> ccnt(submap ? (size_t)off[W] : 0);
+  int ne = 0, nc = 0;
+  check(ctx.get(), vba_hba_add_edge(ctx.get(), W, off.data(), pts.data(), poses.data(), gba_voxel_size, gba_min_eigen_value, eig, max_iter, thread_num,
+                                    edges.data(), &ne, submap ? cloud.data() : nullptr, submap ? ccnt.data() : nullptr, submap ? &nc : nullptr, nullptr, nullptr));
+  for (int i = 0; i < W; i++) { std::memcpy(xs[i].R, &poses[12 * i], 72); std::memcpy(xs[i].p, &poses[12 * i + 9], 24); }
+  std::vector<GbaEdge> out(ne);
+  for (int e = 0; e < ne; e++) {
+    const double *q = &edges[(size_t)e * 20];
+    out[e].i = (int)q[0]; out[e].j = (int)q[1];
+    std::memcpy(out[e].rot, q + 2, 72); std::memcpy(out[e].tra, q + 11, 24); std::memcpy(out[e].v6, q + 14, 48);
+  }
+  if (submap) { submap->resize(nc); for (int k = 0; k < nc; k++) (*submap)[k] = XYZ{(float)cloud[3 * k], (float)cloud[3 * k + 1], (float)cloud[3 * k + 2]}; }
+  return out;
+}
+
 #ifdef VBA_ADAPTER_HAVE_EIGEN
 // Eigen-typed conveniences so reference call sites keep their argument types (Eigen is column-major: converted here).
 inline void to_rowmajor3(const Eigen::Matrix3d &M, double *r) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[3 * i + j] = M(i, j); }
