@@ -213,22 +213,29 @@ __device__ long long *g_k4_stamps = nullptr;   // diagnostic only (VBA_K4_STAMPS
 template <int W, int NB>
 __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *__restrict__ poses, int head, int end,
                                                    double *__restrict__ partial, const int *__restrict__ gate) {
-  if (gate && *gate == 0) return;
+  // The gate (a flag the previous kernel wrote, ~2 us away on another XCD) and the first round of loads are requested
+  // TOGETHER; the early exit is taken only after both are back, so a live pass pays one memory trip here, not two.
+  const int gate_v = gate ? *gate : 1;
   const int v = head + blockIdx.x * 64 + threadIdx.x;
   const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
   double r = 0.0;
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
   long long *stp = g_k4_stamps;
   if (stp) st0 = clock64();
-  if (v < end) {
-    double nn[W];
+  const int vc = v < end ? v : (end > head ? end - 1 : head);      // clamped: the loads below are issued unconditionally
+  double nn[W];
 #pragma unroll
-    for (int i = 0; i < W; i++) nn[i] = f.cl[9 * fs + (size_t)i * vs + v];
-    double P00 = f.fix[0 * vs + v], P01 = f.fix[1 * vs + v], P02 = f.fix[2 * vs + v];
-    double P11 = f.fix[3 * vs + v], P12 = f.fix[4 * vs + v], P22 = f.fix[5 * vs + v];
-    double s0 = f.fix[6 * vs + v], s1 = f.fix[7 * vs + v], s2 = f.fix[8 * vs + v];
-    double N = f.fix[9 * vs + v];
-    const double coe = f.coe[v];
+  for (int i = 0; i < W; i++) nn[i] = f.cl[9 * fs + (size_t)i * vs + vc];
+  double P00 = f.fix[0 * vs + vc], P01 = f.fix[1 * vs + vc], P02 = f.fix[2 * vs + vc];
+  double P11 = f.fix[3 * vs + vc], P12 = f.fix[4 * vs + vc], P22 = f.fix[5 * vs + vc];
+  double s0 = f.fix[6 * vs + vc], s1 = f.fix[7 * vs + vc], s2 = f.fix[8 * vs + vc];
+  double N = f.fix[9 * vs + vc];
+  const double coe = f.coe[vc];
+#pragma unroll
+  for (int i = 0; i < W; i++) asm volatile("" : "+v"(nn[i]));       // keep the loads above the exit (they would be sunk below it)
+  asm volatile("" : "+v"(N));
+  if (gate_v == 0) return;
+  if (v < end) {
     constexpr int WB = (W + NB - 1) / NB;
 #pragma unroll
     for (int bt = 0; bt < NB; bt++) {
@@ -293,12 +300,21 @@ __global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *_
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nb, int nout, double *__restrict__ out,
                                                         const int *__restrict__ gate) {
   __shared__ double s[256];
-  if (gate && *gate == 0) return;
+  const int gate_v = gate ? *gate : 1;            // requested together with the first 16 partials (one memory trip, see k_residual_w)
   const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int o = blockIdx.x * 16 + j;
+  const int o = blockIdx.x * 16 + j, oc = o < nout ? o : nout - 1;
+  double pv[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { const int b = q + 16 * k; pv[k] = partial[(size_t)(b < nb ? b : 0) * nout + oc]; }
+#pragma unroll
+  for (int k = 0; k < 16; k++) asm volatile("" : "+v"(pv[k]));
+  if (gate_v == 0) return;
   double acc = 0.0;
-  if (o < nout)
-    for (int b = q; b < nb; b += 16) acc += partial[(size_t)b * nout + o];
+  if (o < nout) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += (q + 16 * k < nb) ? pv[k] : 0.0;
+    for (int b = q + 256; b < nb; b += 16) acc += partial[(size_t)b * nout + o];
+  }
   s[threadIdx.x] = acc;
   __syncthreads();
   if (q == 0 && o < nout) {
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
                                                              long long *__restrict__ stamps) {
   using C = HessCfg2<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (gate && *gate == 0) return;
+  const int gate_v = gate ? *gate : 1;        // consumed after the first tile's loads have been requested (one trip, not two)
   // diagnostic stamps (stamps == nullptr in production): per workgroup [start, prologue, A0, B0, A1, B1, ..., reduce, end]
 #define VBA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
   VBA_STAMP(0);
@@ -432,6 +448,8 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
   SlotLoad nx;
   nx.valid = false;
   if (slot_thread && (int)blockIdx.x < ntiles) slot_load<W>(f, head + blockIdx.x * C::TV + vl, fi, end, nx);
+  asm volatile("" : "+v"(nx.n));
+  if (gate_v == 0) return;                    // uniform
   __syncthreads();
   VBA_STAMP(1);
   int stamp_i = 2;

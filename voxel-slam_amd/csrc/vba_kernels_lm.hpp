@@ -398,15 +398,22 @@ __global__ __launch_bounds__(64) void k_lm_update(LmDev *s, const double *__rest
   if (lane < 12 * W) xt0 = s->xt[lane];
   if (lane + 64 < 12 * W) xt1 = s->xt[lane + 64];
   if (lane + 128 < 12 * W) xt2 = s->xt[lane + 128];
+  double pv[8];                                           // the residual pass' partials, requested with the state above
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int b = lane + 64 * k; pv[k] = r2_dev[(nb > 0 && b < nb) ? b : 0]; }
+#pragma unroll
+  for (int k = 0; k < 8; k++) asm volatile("" : "+v"(pv[k]));
   if (stop) return;
   double r2;
   if (nb > 0) {
     double acc = 0.0;
-    for (int b = lane; b < nb; b += 64) acc += r2_dev[b];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc += (lane + 64 * k < nb) ? pv[k] : 0.0;
+    for (int b = lane + 512; b < nb; b += 64) acc += r2_dev[b];
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
     r2 = acc;
   } else {
-    r2 = *r2_dev;
+    r2 = pv[0];
   }
   double q = r1 - r2, u = u0, v = v0;
   const bool accept = q > 0;

@@ -79,30 +79,29 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
       const bool is_rhs = (i == rhs_row);
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        // pivot c of the diagonal block (identical in every lane) ...
+        // pivot c of the diagonal block (identical in every lane).  f64 dependent-issue latency is ~40 cycles here, so the
+        // recurrence is arranged to keep the chain pivot -> next pivot short: 1/d by v_rcp_f64 and two Newton steps in
+        // three levels (e^2 is formed beside y1), every update as fma(-(a b), 1/d, .) with the product a b off the chain.
         const double d = D[c][c];
         const bool ok = fabs(d) > 0.0;
-        double inv = __builtin_amdgcn_rcp(d);
-        inv = fma(fma(-d, inv, 1.0), inv, inv);
-        inv = fma(fma(-d, inv, 1.0), inv, inv);
+        const double y0 = __builtin_amdgcn_rcp(d);
+        const double e = fma(-d, y0, 1.0);
+        const double y1 = fma(e, y0, y0), e2 = e * e;
+        const double inv = fma(e2, y1, y1);
         const double dinv = ok ? inv : 0.0;
-        // ... this lane's row, right-looking: l_c is final once columns < c have been applied to x[c]
+        // this lane's row, right-looking: x[c] is final once columns < c have been applied
         double lv = ok ? x[c] * dinv : x[c];
         if (is_rhs) lv = (fabs(d) > 2.2250738585072014e-308) ? x[c] * dinv : 0.0;
         lv = (ib > c) ? lv : 0.0;               // rows of the diagonal block: strictly lower part only
-        const double tmc = lv * d;
+        const double tmc = (ok && ib > c) ? x[c] : 0.0;   // T = L d = the unscaled value (0 for a zero pivot)
         Lk[ib * LS + c] = lv;
         Tp[i * LS + c] = -tmc;
 #pragma unroll
-        for (int r = c + 1; r < 8; r++) D[r][c] = ok ? D[r][c] * inv : D[r][c];      // L[r][c] of the block
+        for (int c2 = c + 1; c2 < 8; c2++) x[c2] = fma(-(tmc * D[c2][c]), dinv, x[c2]);
 #pragma unroll
-        for (int c2 = c + 1; c2 < 8; c2++) x[c2] -= tmc * D[c2][c];
+        for (int r = c + 1; r < 8; r++)
 #pragma unroll
-        for (int r = c + 1; r < 8; r++) {
-          const double t = D[r][c] * d;                                                  // T[r][c]
-#pragma unroll
-          for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] -= t * D[c2][c];
-        }
+          for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] = fma(-(D[r][c] * D[c2][c]), dinv, D[r][c2]);
       }
     }
     __syncthreads();
