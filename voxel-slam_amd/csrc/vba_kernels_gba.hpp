@@ -265,6 +265,7 @@ inline int gba_build(GbaStore &s, hipStream_t st, int W, const int *offsets, con
       }
     }
     GBACHK(hipGetLastError());
+    GBACHK(hipStreamSynchronize(st));   // drain first (see map_read_counters)
     GBACHK(hipMemcpyAsync(s.h_cnt, s.v.cnt, GCNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
     GBACHK(hipStreamSynchronize(st));
     if (s.h_cnt[GCNT_OVERFLOW] == 2) { err = "keyframe point outside the 21-bit voxel index range"; return VBA_ERR_CAPACITY; }

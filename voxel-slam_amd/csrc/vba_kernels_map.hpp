@@ -944,6 +944,7 @@ inline int grow_arrays(std::vector<DevArr> arrs, size_t oldcap, size_t newcap, s
 }
 
 inline int map_read_counters(MapStore &s, hipStream_t st, std::string &err) {
+  MAPCHK(hipStreamSynchronize(st));     // drain first: a D2H copy queued behind in-flight kernels completes much later (measured)
   MAPCHK(hipMemcpyAsync(s.h_cnt, s.v.cnt, CNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
   MAPCHK(hipStreamSynchronize(st));
   s.ub_nodes = s.h_cnt[CNT_NODES]; s.ub_roots = s.h_cnt[CNT_ROOTS]; s.cnt_stale = false;
@@ -1318,6 +1319,7 @@ inline int map_odom_accumulate(MapStore &s, hipStream_t st, const OdomState &X, 
   hipLaunchKernelGGL(k_odom_match, dim3(nb), dim3(256), 0, st, s.v, P, X, n, d_pts, d_var, d_partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, st, d_partial, nb, 34, d_out34, (const int *)nullptr);
   MAPCHK(hipGetLastError());
+  MAPCHK(hipStreamSynchronize(st));
   MAPCHK(hipMemcpyAsync(out34, d_out34, 34 * sizeof(double), hipMemcpyDeviceToHost, st));
   MAPCHK(hipStreamSynchronize(st));
   return VBA_OK;

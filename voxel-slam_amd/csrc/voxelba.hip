@@ -343,6 +343,7 @@ int fetch(vba_ctx *c, const double *d_src, size_t n, double *dst) {
   int st = ensure_pin(c, n + 65536);
   if (st) return st;
   double *stage = c->h_pin + 32768;  // poses live in the first part
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // drain first: a D2H copy queued behind in-flight kernels completes much later (measured)
   HIPCHK(c, hipMemcpyAsync(stage, d_src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(dst, stage, n * sizeof(double));
@@ -654,6 +655,7 @@ int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (!c->lm.active) return VBA_ERR_BAD_ARG;
   const int W = c->opt.win_size, n = 6 * W;
   if (!poses && !hess && !resis2) { c->lm.active = false; return VBA_OK; }    // nothing requested: no synchronisation
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // drain first (D2H copies queued behind in-flight kernels complete much later, see li_ba_device)
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
   if (hess) {
     int st = ensure_pin(c, 65536 + (size_t)n * n + 1024);
@@ -810,7 +812,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     HIPCHK(c, hipGetLastError());
   }
   const double t_enq = since(t_0);
-  if (want_times) { hipStreamSynchronize(c->stream); }
+  // drain first: D2H copies queued behind in-flight kernels were measured 2-3x slower end to end than copies issued on an idle
+  // stream (545 vs 231 us per LM iteration inside bench.py)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   const double t_gpu = since(t_0);
   // download: accepted state, the factors' bias increments, trace, and (on request) *hess = Hess before gauge fixing —
   // everything lands in ONE pinned block (pageable destinations make every copy a blocking staged transfer)
@@ -1245,6 +1249,7 @@ int vba_scan_down_sampling_voxel(vba_ctx *c, int n, const double *pnt, double vo
   span_end(c, "downsample", sp);
   HIPCHK(c, hipGetLastError());
   int m = 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpyAsync(&m, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (m > 0) {
