@@ -54,8 +54,11 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (s->stop || !s->is_calc_hess) return;
   const int W = li->W, F = li->F, nb = li->nb, n = li->n, grav = li->gravity, tid = threadIdx.x;
-  double *joc = lds, *cj = joc + (size_t)F * 15 * nb, *rr = cj + (size_t)F * 15 * nb, *cr = rr + F * 15, *qf = cr + F * 15;
+  long long *stp = ((s->pad & 64) && tid == 0) ? const_cast<long long *>(s->stamps) + 40 : nullptr;   // diagnostic
+  if (stp) stp[0] = clock64();
+  double *joc = lds, *cj = joc + (size_t)F * 15 * nb, *rr = cj + (size_t)F * 15 * nb, *cr = rr + F * 15, *qf = cr + F * 15, *cinv = qf + ((F + 1) & ~1);
   for (int t = tid; t < F * 15 * nb; t += 256) joc[t] = 0.0;
+  for (int t = tid; t < F * 225; t += 256) cinv[t] = imu[304 * (size_t)(t / 225) + 79 + t % 225];
   __syncthreads();
   if (tid < F) {
     vbh::State s1, s2;
@@ -64,23 +67,37 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
     vbh::imu_residual_jacobian(*reinterpret_cast<const vbh::ImuPre *>(imu + 304 * (size_t)tid), s1, s2, grav != 0, rr + 15 * tid, joc + (size_t)tid * 15 * nb, nb);
   }
   __syncthreads();
-  for (int f = 0; f < F; f++) {                              // cj_f = cov^-1 joc_f
-    const double *jf = joc + (size_t)f * 15 * nb, *cv = imu + 304 * (size_t)f + 79;
-    for (int t = tid; t < 15 * nb; t += 256) {
-      const int k = t / nb, c = t - k * nb;
-      double a = 0;
-      for (int k2 = 0; k2 < 15; k2++) a += cv[15 * k + k2] * jf[k2 * nb + c];
-      cj[(size_t)f * 15 * nb + t] = a;
+  if (stp) stp[1] = clock64();
+  {   // cj_f = cov^-1 joc_f in 3 x 3 register tiles (6 LDS loads per 9 FMAs; one output per thread was LDS-bandwidth bound)
+    const int ncb = nb / 3, ntask = F * 5 * ncb;
+    for (int t = tid; t < ntask; t += 256) {
+      const int f = t / (5 * ncb), rem = t - f * 5 * ncb, kb = rem / ncb, cb = rem - kb * ncb;
+      const double *jf = joc + (size_t)f * 15 * nb + 3 * cb, *cv = cinv + (size_t)f * 225 + 45 * kb;
+      double a[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 5
+      for (int k2 = 0; k2 < 15; k2++) {
+        const double j0 = jf[k2 * nb], j1 = jf[k2 * nb + 1], j2 = jf[k2 * nb + 2];
+        const double c0 = cv[k2], c1 = cv[15 + k2], c2 = cv[30 + k2];
+        a[0][0] += c0 * j0; a[0][1] += c0 * j1; a[0][2] += c0 * j2;
+        a[1][0] += c1 * j0; a[1][1] += c1 * j1; a[1][2] += c1 * j2;
+        a[2][0] += c2 * j0; a[2][1] += c2 * j1; a[2][2] += c2 * j2;
+      }
+      double *o = cj + (size_t)f * 15 * nb + (size_t)(3 * kb) * nb + 3 * cb;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[r * nb + c] = a[r][c];
     }
   }
   if (tid < F * 15) {
     const int f = tid / 15, k = tid % 15;
-    const double *ci = imu + 304 * (size_t)f + 79 + 15 * k;
+    const double *ci = cinv + (size_t)f * 225 + 15 * k;
     double a = 0;
     for (int k2 = 0; k2 < 15; k2++) a += ci[k2] * rr[15 * f + k2];
     cr[tid] = a;
   }
   __syncthreads();
+  if (stp) stp[2] = clock64();
   if (tid < F) { double q = 0; for (int k = 0; k < 15; k++) q += rr[15 * tid + k] * cr[15 * tid + k]; qf[tid] = q; }
   // jtj_f(lr, lc) = sum_k joc_f[k][lr] cj_f[k][lc]
   auto jtj = [&](int f, int lr, int lc) -> double {
@@ -89,17 +106,35 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
     for (int k = 0; k < 15; k++) a += jf[k * nb] * cf[k * nb];
     return a;
   };
-  // state blocks: the (a, b) pair is uniform per iteration, every thread keeps one (r, c) of the 15 x 15 block
-  if (tid < 225) {
-    const int r = tid / 15, c = tid - 15 * r;
-    for (int a = 0; a < W; a++)
-      for (int b = (a > 0 ? a - 1 : 0); b <= (a + 1 < W ? a + 1 : W - 1); b++) {
-        double acc = 0;
-        if (b == a) { if (a >= 1) acc += jtj(a - 1, 15 + r, 15 + c); if (a <= W - 2) acc += jtj(a, r, c); }
-        else if (b == a + 1) acc = jtj(a, r, 15 + c);
-        else acc = jtj(b, 15 + r, c);
-        himu[li_hb_pair(a, b) + 15 * r + c] = acc;
+  // state blocks in 3 x 3 register tiles: task = (block pair (a, b), tile); <= 2 factors contribute, ascending
+  {
+    const int npair = 3 * W - 2;
+    for (int t = tid; t < npair * 25; t += 256) {
+      const int pr = t / 25, tile = t - 25 * pr, r0 = 3 * (tile / 5), c0 = 3 * (tile % 5);
+      const int a = (pr + 1) / 3, b = a + ((pr + 1) % 3) - 1;
+      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int pass = 0; pass < 2; pass++) {
+        int f, ro, co;
+        if (b == a) { if (pass == 0) { f = a - 1; ro = 15; co = 15; } else { f = a; ro = 0; co = 0; } }
+        else if (b == a + 1) { if (pass) continue; f = a; ro = 0; co = 15; }
+        else { if (pass) continue; f = b; ro = 15; co = 0; }
+        if (f < 0 || f >= F) continue;
+        const double *jf = joc + (size_t)f * 15 * nb + ro + r0, *cf = cj + (size_t)f * 15 * nb + co + c0;
+#pragma unroll 5
+        for (int k = 0; k < 15; k++) {
+          const double j0 = jf[k * nb], j1 = jf[k * nb + 1], j2 = jf[k * nb + 2];
+          const double q0 = cf[k * nb], q1 = cf[k * nb + 1], q2 = cf[k * nb + 2];
+          acc[0][0] += j0 * q0; acc[0][1] += j0 * q1; acc[0][2] += j0 * q2;
+          acc[1][0] += j1 * q0; acc[1][1] += j1 * q1; acc[1][2] += j1 * q2;
+          acc[2][0] += j2 * q0; acc[2][1] += j2 * q1; acc[2][2] += j2 * q2;
+        }
       }
+      double *o = himu + li_hb_pair(a, b) + 15 * r0 + c0;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[15 * r + c] = acc[r][c];
+    }
   }
   if (grav) {                                                // gravity border VM:788-795 and the 3 x 3 corner
     for (int e = tid; e < 15 * W * 3; e += 256) {
@@ -135,6 +170,7 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
     gimu[tid] = acc;
   }
   __syncthreads();
+  if (stp) stp[3] = clock64();
   if (tid == 0) { double q = 0; for (int f = 0; f < F; f++) q += qf[f]; li->rimu[0] = q; }
 }
 

@@ -759,7 +759,11 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const int *run_hess = reinterpret_cast<const int *>(base + offsetof(LmDev, run_hess));
   const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
   const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
-  const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16) * sizeof(double);
+  const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16 + (size_t)F * 225) * sizeof(double);
+  {
+    static bool attr_set = false;      // W = 10 with gravity: 88 KB
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * 9 * 15 * 33 + 2 * 9 * 15 + 9 + 16 + 9 * 225) * sizeof(double))); attr_set = true; }
+  }
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
     // the IMU factors (one workgroup) run on a side stream under the lidar Hessian pass; both only read the LM state
@@ -861,6 +865,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     for (int kb = 0; kb < 20; kb++) fprintf(stderr, " %lld+%lld", hl->stamps[9 + 2 * kb] - hl->stamps[8 + 2 * kb], kb < 19 ? hl->stamps[10 + 2 * kb] - hl->stamps[9 + 2 * kb] : 0LL);
     fprintf(stderr, "\n");
   }
+  if (want_times && (hl->pad & 64)) fprintf(stderr, "[k_li_imu cycles] factor algebra (one lane per factor) %lld | cov^-1 joc %lld | contractions %lld\n", hl->stamps[41] - hl->stamps[40], hl->stamps[42] - hl->stamps[41], hl->stamps[43] - hl->stamps[42]);
   if (want_times && (hl->pad & 32)) { double v[6]; std::memcpy(v, &hl->stamps[58], sizeof(v)); fprintf(stderr, "[li r1 parts] rank %d: rimu %.10g lidar %.10g | %.10g %.10g | %.10g %.10g\n", c->rank, v[0], v[1], v[2], v[3], v[4], v[5]); }
   if (want_times) fprintf(stderr, "[li_ba_device] upload %.1f us | enqueue %.1f | gpu drained at %.1f | total %.1f\n", t_up, t_enq - t_up, t_gpu, since(t_0));
   return VBA_OK;
