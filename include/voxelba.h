@@ -164,6 +164,14 @@ int vba_scan_var_init(vba_ctx *ctx, int n, const double *pnt_in, const double *e
  * voxel_size < 0.001 returns the input unchanged (TL:203), counts 0.  Buffers may be HOST or DEVICE memory. */
 int vba_scan_down_sampling_voxel(vba_ctx *ctx, int n, const double *pnt, double voxel_size, double *pnt_out, int *count_out,
                                  int *first_out, int *n_out);
+/* down_sampling_pvec (voxel_map.hpp:39-83): the pointVar form used when a keyframe cloud is made (VS:2385): double
+ * coordinates pnt [n][3] and covariances var [n][9] -> per voxel the mean point and the mean covariance DIAGONAL
+ * (stored by the reference in normal_x/y/z), both narrowed to float like the PCL points they become. */
+int vba_scan_down_sampling_pvec(vba_ctx *ctx, int n, const double *pnt, const double *var, double voxel_size,
+                                double *pnt_out, double *vardiag_out, int *count_out, int *n_out);
+/* down_sampling_close (tools.hpp:240-298): per voxel the index of the input point closest to the voxel's centroid
+ * (first such point; only squared distances < 100 compete, else the voxel's first point — TL:281-295). */
+int vba_scan_down_sampling_close(vba_ctx *ctx, int n, const double *pnt, double voxel_size, int *index_out, int *n_out);
 /* Undistortion inner loop of IMUEKF::motion_blur (ekf_imu.hpp:137-163).  pnt [n][3] in/out, curv [n] = per-point time
  * offset (PointType::curvature), ascending as pcl_handler leaves them (VH:92-95); imu_poses [m][22] = the imu_poses
  * vector (EK:87): t, R[9], p[3], v[3], angvel_avr[3], acc_imu[3]; end_pose [12] = xc.R, xc.p after propagation

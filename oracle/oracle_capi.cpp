@@ -303,6 +303,25 @@ int vso_down_sampling_voxel(int n, const double *pnt, double voxel_size, double 
   }
   return (int)o.size();
 }
+int vso_down_sampling_pvec(int n, const double *pnt, const double *var, double voxel_size, double *out, double *vdiag, int *count) {
+  std::vector<V3> p(n); std::vector<M3> v(n);
+  for (int i = 0; i < n; i++) { p[i] = v3_from(pnt + 3 * i); v[i] = m3_from(var + 9 * i); }
+  std::vector<DsPvec> o;
+  down_sampling_pvec(p, v, voxel_size, o);
+  for (size_t i = 0; i < o.size(); i++) {
+    out[3 * i] = o[i].x; out[3 * i + 1] = o[i].y; out[3 * i + 2] = o[i].z;
+    vdiag[3 * i] = o[i].nx; vdiag[3 * i + 1] = o[i].ny; vdiag[3 * i + 2] = o[i].nz; count[i] = o[i].count;
+  }
+  return (int)o.size();
+}
+int vso_down_sampling_close(int n, const double *pnt, double voxel_size, int *keep) {
+  std::vector<V3> p(n);
+  for (int i = 0; i < n; i++) p[i] = v3_from(pnt + 3 * i);
+  std::vector<int> k;
+  down_sampling_close(p, voxel_size, k);
+  for (size_t i = 0; i < k.size(); i++) keep[i] = k[i];
+  return (int)k.size();
+}
 // motion_blur point loop (ekf_imu.hpp:137-163): pnt [n][3] in/out (float values), imu_poses [m][22] = t R p v angvel acc
 void vso_undistort(int n, double *pnt, const double *curv, int m, const double *imu_poses, const double *end_pose, const double *ext_pose) {
   std::vector<float> pts(3 * (size_t)n), cv(n);

@@ -198,6 +198,22 @@ def down_sampling_voxel(pnt, voxel_size):
     return out[:m].copy(), cnt[:m].copy(), first[:m].copy()
 
 
+def down_sampling_pvec(pnt, var, voxel_size):
+    pnt = _c(pnt); var = _c(var); n = len(pnt)
+    out = np.empty((max(n, 1), 3)); vd = np.empty((max(n, 1), 3)); cnt = np.zeros(max(n, 1), dtype=np.int32)
+    lib().vso_down_sampling_pvec.restype = C.c_int
+    m = lib().vso_down_sampling_pvec(C.c_int(n), _p(pnt), _p(var), C.c_double(voxel_size), _p(out), _p(vd), cnt.ctypes.data_as(C.POINTER(C.c_int)))
+    return out[:m].copy(), vd[:m].copy(), cnt[:m].copy()
+
+
+def down_sampling_close(pnt, voxel_size):
+    pnt = _c(pnt); n = len(pnt)
+    keep = np.zeros(max(n, 1), dtype=np.int32)
+    lib().vso_down_sampling_close.restype = C.c_int
+    m = lib().vso_down_sampling_close(C.c_int(n), _p(pnt), C.c_double(voxel_size), keep.ctypes.data_as(C.POINTER(C.c_int)))
+    return keep[:m].copy()
+
+
 def undistort(pnt, curv, imu_poses22, end_pose12, ext_pose12):
     pnt = _c(pnt).copy(); curv = _c(curv); ip = _c(imu_poses22)
     lib().vso_undistort(C.c_int(len(pnt)), _p(pnt), _p(curv), C.c_int(len(ip)), _p(ip), _p(_c(end_pose12)), _p(_c(ext_pose12)))

@@ -74,3 +74,35 @@ def test_undistort_parity(oracle, n, m):
     np.testing.assert_allclose(got, want, rtol=0, atol=np.spacing(np.float32(np.abs(want).max())) * 1.01)
     assert np.mean(got == want) > 0.99
     ctx.close()
+
+
+def test_down_sampling_pvec_parity(oracle):
+    """voxel_map.hpp:39-83 (keyframe cloud of VS:2385): mean point and mean covariance diagonal per voxel."""
+    rng = np.random.default_rng(21)
+    n = 60000
+    pnt = rng.uniform(-15, 15, (n, 3)); pnt[: n // 2] *= 0.1
+    A = rng.normal(0, 0.02, (n, 3, 3)); var = (A @ A.transpose(0, 2, 1)).reshape(n, 9)
+    ctx = _ctx()
+    out, vd, cnt = ctx.down_sampling_pvec(pnt, var, 0.2)
+    o_out, o_vd, o_cnt = oracle.down_sampling_pvec(pnt, var, 0.2)
+    assert len(out) == len(o_out) and cnt.sum() == n
+    np.testing.assert_array_equal(cnt, o_cnt)                          # same voxels in the same (first-occurrence) order
+    np.testing.assert_allclose(out, o_out, rtol=0, atol=4e-6)          # running mean in double vs sum / n, then float
+    np.testing.assert_allclose(vd, o_vd, rtol=2e-6, atol=1e-12)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,voxel", [(50000, 0.3), (3000, 0.05)])
+def test_down_sampling_close_parity(oracle, n, voxel):
+    """tools.hpp:240-298: the input point closest to its voxel's centroid is kept."""
+    rng = np.random.default_rng(31 + n)
+    pts = rng.uniform(-12, 12, (n, 3)).astype(np.float32).astype(np.float64)
+    pts[: n // 3] = (pts[: n // 3] * 0.05).astype(np.float32)
+    ctx = _ctx()
+    keep = ctx.down_sampling_close(pts, voxel)
+    o_keep = oracle.down_sampling_close(pts, voxel)
+    assert len(keep) == len(o_keep)
+    # the reference sums the centroid in float in input order, the device in f64: near-ties between two candidates may flip
+    assert np.mean(keep == o_keep) > 0.998
+    assert len(set(keep.tolist())) == len(keep) and keep.min() >= 0 and keep.max() < n
+    ctx.close()

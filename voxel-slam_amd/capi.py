@@ -26,7 +26,7 @@ EXPORTS = [
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
-    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_undistort", "vba_gba_build", "vba_hba_add_edge", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
+    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_gba_build", "vba_hba_add_edge", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
@@ -276,6 +276,19 @@ class Context:
         self._chk(self.lib.vba_scan_down_sampling_voxel(self.h, C.c_int(n), _p(pnt), C.c_double(voxel_size), _p(out),
                                                         cnt.ctypes.data_as(C.POINTER(C.c_int)), first.ctypes.data_as(C.POINTER(C.c_int)), C.byref(m)))
         return out[:m.value].copy(), cnt[:m.value].copy(), first[:m.value].copy()
+
+    def down_sampling_pvec(self, pnt, var, voxel_size):
+        pnt = _c(pnt); var = _c(var); n = len(pnt)
+        out = np.empty((max(n, 1), 3)); vd = np.empty((max(n, 1), 3)); cnt = np.zeros(max(n, 1), dtype=np.int32); m = C.c_int(0)
+        self._chk(self.lib.vba_scan_down_sampling_pvec(self.h, C.c_int(n), _p(pnt), _p(var), C.c_double(voxel_size), _p(out), _p(vd),
+                                                       cnt.ctypes.data_as(C.POINTER(C.c_int)), C.byref(m)))
+        return out[:m.value].copy(), vd[:m.value].copy(), cnt[:m.value].copy()
+
+    def down_sampling_close(self, pnt, voxel_size):
+        pnt = _c(pnt); n = len(pnt)
+        idx = np.zeros(max(n, 1), dtype=np.int32); m = C.c_int(0)
+        self._chk(self.lib.vba_scan_down_sampling_close(self.h, C.c_int(n), _p(pnt), C.c_double(voxel_size), idx.ctypes.data_as(C.POINTER(C.c_int)), C.byref(m)))
+        return idx[:m.value].copy()
 
     def undistort(self, pnt, curv, imu_poses22, end_pose12, ext_pose12):
         pnt = _c(pnt).copy(); curv = _c(curv); ip = _c(imu_poses22)

@@ -11,12 +11,15 @@ namespace vba {
 struct DsSlot {
   unsigned long long key;      // packed voxel index, DS_EMPTY when free
   double sx, sy, sz;
-  int cnt, first;
+  double vx, vy, vz;           // down_sampling_pvec: sums of the covariance diagonals
+  unsigned long long mind;     // down_sampling_close: smallest squared distance to the centroid (bits of a non-negative double)
+  int cnt, first, best, pad;
 };
 static constexpr unsigned long long DS_EMPTY = ~0ull;
 
-__device__ __forceinline__ long long ds_axis_key(double v, double voxel_size) {   // TL:210-217 on PCL float coordinates
-  float loc = (float)((double)(float)v / voxel_size);
+// TL:210-217 on PCL float coordinates; dbl != 0: the pointVar form of VM:45-51 (double coordinates)
+__device__ __forceinline__ long long ds_axis_key(double v, double voxel_size, int dbl = 0) {
+  float loc = (float)((dbl ? v : (double)(float)v) / voxel_size);
   if (loc < 0) loc = (float)((double)loc - 1.0);
   return (long long)loc;
 }
@@ -31,25 +34,29 @@ __device__ __forceinline__ unsigned int ds_hash(unsigned long long k) {
 __global__ void k_ds_clear(DsSlot *__restrict__ tab, int cap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
-  DsSlot s; s.key = DS_EMPTY; s.sx = s.sy = s.sz = 0.0; s.cnt = 0; s.first = 0x7fffffff;
+  DsSlot s; s.key = DS_EMPTY; s.sx = s.sy = s.sz = 0.0; s.vx = s.vy = s.vz = 0.0; s.mind = ~0ull; s.cnt = 0; s.first = 0x7fffffff; s.best = 0x7fffffff; s.pad = 0;
   tab[i] = s;
 }
 
 // point -> slot (open addressing, linear probing), sums, count, first point of the voxel
-__global__ void k_ds_insert(int n, const double *__restrict__ pnt, double voxel_size, DsSlot *__restrict__ tab, int cap_mask, int *__restrict__ slot_of) {
+// var != nullptr: pointVar input (down_sampling_pvec, VM:39-83): double coordinates, the covariance diagonal is averaged too
+__global__ void k_ds_insert(int n, const double *__restrict__ pnt, const double *__restrict__ var, double voxel_size, DsSlot *__restrict__ tab, int cap_mask,
+                            int *__restrict__ slot_of) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int dbl = var != nullptr;
   const double x = pnt[3 * (size_t)i], y = pnt[3 * (size_t)i + 1], z = pnt[3 * (size_t)i + 2];
-  const unsigned long long key = ds_pack(ds_axis_key(x, voxel_size), ds_axis_key(y, voxel_size), ds_axis_key(z, voxel_size));
+  const unsigned long long key = ds_pack(ds_axis_key(x, voxel_size, dbl), ds_axis_key(y, voxel_size, dbl), ds_axis_key(z, voxel_size, dbl));
   unsigned int h = ds_hash(key) & cap_mask;
   for (int probe = 0; probe <= cap_mask; probe++) {          // the table has >= 2n slots: always terminates
     const unsigned long long old = atomicCAS(&tab[h].key, DS_EMPTY, key);
     if (old == DS_EMPTY || old == key) break;
     h = (h + 1) & cap_mask;
   }
-  atomicAdd(&tab[h].sx, (double)(float)x);
-  atomicAdd(&tab[h].sy, (double)(float)y);
-  atomicAdd(&tab[h].sz, (double)(float)z);
+  atomicAdd(&tab[h].sx, dbl ? x : (double)(float)x);
+  atomicAdd(&tab[h].sy, dbl ? y : (double)(float)y);
+  atomicAdd(&tab[h].sz, dbl ? z : (double)(float)z);
+  if (dbl) { atomicAdd(&tab[h].vx, var[9 * (size_t)i]); atomicAdd(&tab[h].vy, var[9 * (size_t)i + 4]); atomicAdd(&tab[h].vz, var[9 * (size_t)i + 8]); }
   atomicAdd(&tab[h].cnt, 1);
   atomicMin(&tab[h].first, i);
   slot_of[i] = h;
@@ -81,8 +88,10 @@ __global__ __launch_bounds__(256) void k_ds_scan(int nb, int *__restrict__ blk, 
 }
 
 // stable compaction in first-occurrence order; centroid rounded to float like the PCL cloud it replaces
+// mode 0: centroid (down_sampling_voxel); 1: centroid + mean covariance diagonal in vout (down_sampling_pvec);
+// 2: first[] receives the index of the point closest to the centroid (down_sampling_close), out = that point's voxel centroid
 __global__ __launch_bounds__(256) void k_ds_emit(int n, const DsSlot *__restrict__ tab, const int *__restrict__ slot_of, const int *__restrict__ blk,
-                                                 double *__restrict__ out, int *__restrict__ count, int *__restrict__ first) {
+                                                 double *__restrict__ out, int *__restrict__ count, int *__restrict__ first, double *__restrict__ vout, int mode) {
   __shared__ int wsum[4];
   const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   DsSlot s;
@@ -99,7 +108,30 @@ __global__ __launch_bounds__(256) void k_ds_emit(int n, const DsSlot *__restrict
   out[3 * (size_t)pos + 1] = (double)(float)(s.sy * inv);
   out[3 * (size_t)pos + 2] = (double)(float)(s.sz * inv);
   count[pos] = s.cnt;
-  first[pos] = i;
+  first[pos] = (mode == 2) ? ((s.best != 0x7fffffff) ? s.best : i) : i;
+  if (mode == 1) {
+    vout[3 * (size_t)pos] = (double)(float)(s.vx * inv); vout[3 * (size_t)pos + 1] = (double)(float)(s.vy * inv); vout[3 * (size_t)pos + 2] = (double)(float)(s.vz * inv);
+  }
+}
+
+// down_sampling_close (tools.hpp:240-298): per voxel the point with the smallest squared distance to the (float) centroid,
+// first such point in input order, only distances < 100 compete (ndis = 100, mnum = 0 at TL:281-282).
+__global__ void k_ds_close_min(int n, const double *__restrict__ pnt, DsSlot *__restrict__ tab, const int *__restrict__ slot_of, double *__restrict__ dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  DsSlot *s = tab + slot_of[i];
+  const double inv = 1.0 / (double)s->cnt;
+  const float cx = (float)(s->sx * inv), cy = (float)(s->sy * inv), cz = (float)(s->sz * inv);
+  const double xx = (double)(cx - (float)pnt[3 * (size_t)i]), yy = (double)(cy - (float)pnt[3 * (size_t)i + 1]), zz = (double)(cz - (float)pnt[3 * (size_t)i + 2]);
+  const double d = xx * xx + yy * yy + zz * zz;
+  dist[i] = d;
+  if (d < 100.0) atomicMin(&s->mind, (unsigned long long)__double_as_longlong(d));
+}
+__global__ void k_ds_close_arg(int n, DsSlot *__restrict__ tab, const int *__restrict__ slot_of, const double *__restrict__ dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  DsSlot *s = tab + slot_of[i];
+  if ((unsigned long long)__double_as_longlong(dist[i]) == s->mind) atomicMin(&s->best, i);
 }
 
 // ---------------------------------------------------------------- undistortion

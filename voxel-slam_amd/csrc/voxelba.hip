@@ -1216,16 +1216,18 @@ int vba_scan_var_init(vba_ctx *c, int n, const double *pnt_in, const double *ext
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return VBA_OK;
 }
-int vba_scan_down_sampling_voxel(vba_ctx *c, int n, const double *pnt, double voxel_size, double *pnt_out, int *count_out, int *first_out,
-                                 int *n_out) {
-  if (n < 0 || !n_out || (n > 0 && (!pnt || !pnt_out || !count_out || !first_out))) return VBA_ERR_BAD_ARG;
+// mode 0 down_sampling_voxel, 1 down_sampling_pvec (var in, vout out), 2 down_sampling_close (first_out = chosen indices)
+static int ds_common(vba_ctx *c, int mode, int n, const double *pnt, const double *var, double voxel_size, double *pnt_out, double *vout, int *count_out,
+                     int *first_out, int *n_out) {
+  if (n < 0 || !n_out || (n > 0 && (!pnt || !first_out)) || (mode != 2 && n > 0 && (!pnt_out || !count_out)) || (mode == 1 && n > 0 && (!var || !vout)))
+    return VBA_ERR_BAD_ARG;
   *n_out = 0;
   if (n == 0) return VBA_OK;
-  if (voxel_size < 0.001) {                                             // TL:203
-    HIPCHK(c, hipMemcpyAsync(pnt_out, pnt, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  if (voxel_size < 0.001 && mode != 1) {                                // TL:203 / TL:242: the cloud is left untouched
+    if (pnt_out) HIPCHK(c, hipMemcpyAsync(pnt_out, pnt, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
     std::vector<int> z(n, 0), id(n);
     for (int i = 0; i < n; i++) id[i] = i;
-    HIPCHK(c, hipMemcpyAsync(count_out, z.data(), (size_t)n * sizeof(int), hipMemcpyDefault, c->stream));
+    if (count_out) HIPCHK(c, hipMemcpyAsync(count_out, z.data(), (size_t)n * sizeof(int), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(first_out, id.data(), (size_t)n * sizeof(int), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *n_out = n;
@@ -1235,22 +1237,29 @@ int vba_scan_down_sampling_voxel(vba_ctx *c, int n, const double *pnt, double vo
   while (cap < 2 * n) cap <<= 1;
   const int nb = (n + 255) / 256;
   const size_t b_tab = (size_t)cap * sizeof(DsSlot), b_pnt = (size_t)n * 3 * sizeof(double), b_i = (((size_t)n * sizeof(int)) + 15) & ~(size_t)15,
-               b_blk = (((size_t)nb + 1) * sizeof(int) + 15) & ~(size_t)15;
-  int st = ensure_stage(c, b_tab + 2 * b_pnt + 3 * b_i + b_blk + 64);
+               b_blk = (((size_t)nb + 1) * sizeof(int) + 15) & ~(size_t)15, b_var = mode == 1 ? (size_t)n * 9 * sizeof(double) : 0,
+               b_dist = mode == 2 ? (size_t)n * sizeof(double) : 0;
+  int st = ensure_stage(c, b_tab + 3 * b_pnt + b_var + b_dist + 3 * b_i + b_blk + 64);
   if (st) return st;
   char *base = (char *)c->d_stage;
   DsSlot *tab = (DsSlot *)base;
-  double *d_in = (double *)(base + b_tab), *d_out = (double *)(base + b_tab + b_pnt);
-  int *d_slot = (int *)(base + b_tab + 2 * b_pnt), *d_cnt = (int *)((char *)d_slot + b_i), *d_first = (int *)((char *)d_cnt + b_i),
+  double *d_in = (double *)(base + b_tab), *d_out = (double *)(base + b_tab + b_pnt), *d_vout = (double *)(base + b_tab + 2 * b_pnt),
+         *d_var = (double *)(base + b_tab + 3 * b_pnt), *d_dist = (double *)(base + b_tab + 3 * b_pnt + b_var);
+  int *d_slot = (int *)(base + b_tab + 3 * b_pnt + b_var + b_dist), *d_cnt = (int *)((char *)d_slot + b_i), *d_first = (int *)((char *)d_cnt + b_i),
       *d_blk = (int *)((char *)d_first + b_i), *d_n = d_blk + nb;
   HIPCHK(c, hipMemcpyAsync(d_in, pnt, b_pnt, hipMemcpyDefault, c->stream));
+  if (mode == 1) HIPCHK(c, hipMemcpyAsync(d_var, var, b_var, hipMemcpyDefault, c->stream));
   TimedSpan sp{};
   span_begin(c, "downsample", sp);
   hipLaunchKernelGGL(k_ds_clear, dim3((cap + 255) / 256), dim3(256), 0, c->stream, tab, cap);
-  hipLaunchKernelGGL(k_ds_insert, dim3(nb), dim3(256), 0, c->stream, n, d_in, voxel_size, tab, cap - 1, d_slot);
+  hipLaunchKernelGGL(k_ds_insert, dim3(nb), dim3(256), 0, c->stream, n, d_in, mode == 1 ? d_var : nullptr, voxel_size, tab, cap - 1, d_slot);
+  if (mode == 2) {
+    hipLaunchKernelGGL(k_ds_close_min, dim3(nb), dim3(256), 0, c->stream, n, d_in, tab, d_slot, d_dist);
+    hipLaunchKernelGGL(k_ds_close_arg, dim3(nb), dim3(256), 0, c->stream, n, tab, d_slot, d_dist);
+  }
   hipLaunchKernelGGL(k_ds_count, dim3(nb), dim3(256), 0, c->stream, n, tab, d_slot, d_blk);
   hipLaunchKernelGGL(k_ds_scan, dim3(1), dim3(256), 0, c->stream, nb, d_blk, d_n);
-  hipLaunchKernelGGL(k_ds_emit, dim3(nb), dim3(256), 0, c->stream, n, tab, d_slot, d_blk, d_out, d_cnt, d_first);
+  hipLaunchKernelGGL(k_ds_emit, dim3(nb), dim3(256), 0, c->stream, n, tab, d_slot, d_blk, d_out, d_cnt, d_first, d_vout, mode);
   span_end(c, "downsample", sp);
   HIPCHK(c, hipGetLastError());
   int m = 0;
@@ -1258,13 +1267,26 @@ int vba_scan_down_sampling_voxel(vba_ctx *c, int n, const double *pnt, double vo
   HIPCHK(c, hipMemcpyAsync(&m, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (m > 0) {
-    HIPCHK(c, hipMemcpyAsync(pnt_out, d_out, (size_t)m * 3 * sizeof(double), hipMemcpyDefault, c->stream));
-    HIPCHK(c, hipMemcpyAsync(count_out, d_cnt, (size_t)m * sizeof(int), hipMemcpyDefault, c->stream));
+    if (pnt_out) HIPCHK(c, hipMemcpyAsync(pnt_out, d_out, (size_t)m * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+    if (count_out) HIPCHK(c, hipMemcpyAsync(count_out, d_cnt, (size_t)m * sizeof(int), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(first_out, d_first, (size_t)m * sizeof(int), hipMemcpyDefault, c->stream));
+    if (mode == 1) HIPCHK(c, hipMemcpyAsync(vout, d_vout, (size_t)m * 3 * sizeof(double), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   *n_out = m;
   return VBA_OK;
+}
+int vba_scan_down_sampling_voxel(vba_ctx *c, int n, const double *pnt, double voxel_size, double *pnt_out, int *count_out, int *first_out,
+                                 int *n_out) {
+  return ds_common(c, 0, n, pnt, nullptr, voxel_size, pnt_out, nullptr, count_out, first_out, n_out);
+}
+int vba_scan_down_sampling_pvec(vba_ctx *c, int n, const double *pnt, const double *var, double voxel_size, double *pnt_out, double *vardiag_out,
+                                int *count_out, int *n_out) {
+  std::vector<int> first(n > 0 ? n : 1);
+  return ds_common(c, 1, n, pnt, var, voxel_size, pnt_out, vardiag_out, count_out, first.data(), n_out);
+}
+int vba_scan_down_sampling_close(vba_ctx *c, int n, const double *pnt, double voxel_size, int *index_out, int *n_out) {
+  return ds_common(c, 2, n, pnt, nullptr, voxel_size, nullptr, nullptr, nullptr, index_out, n_out);
 }
 int vba_scan_undistort(vba_ctx *c, int n, double *pnt, const double *curv, int m, const double *imu_poses, const double *end_pose,
                        const double *ext_pose) {
