@@ -382,6 +382,8 @@ __global__ void k_extract_count(MapView m, MapParams P, int multi) {
   m.nopt[id] = atomicAdd(&m.cnt[CNT_FACTORS], 1);        // opt_state  VM:1626
 }
 // pass 2: write the SoA factor store (push_voxel VM:139-147), frames in ring order pcrs[i] = pcrs_local[mp[i]] VM:1623-1624.
+// One thread per (node, row of the voxel's SoA record): rows 0..10W-1 = the body clusters, then fix (10), pcr (10), coe,
+// eigval (3), eigvec (9).  (One thread per node copying all 10W+33 scalars was latency-bound: 58 us for 26k factors.)
 __global__ void k_extract_write(MapView m, MapParams P, FactorView f, int multi) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
@@ -391,14 +393,18 @@ __global__ void k_extract_write(MapView m, MapParams P, FactorView f, int multi)
   const int a = m.nopt[id];
   if (a < 0 || a >= f.vs) return;
   const size_t cp = (size_t)m.cap, vs = (size_t)f.vs, W = (size_t)P.W;
-  for (int i = 0; i < P.W; i++) {
-    const int slot = P.mp[i];
-    for (int k = 0; k < 10; k++) f.cl[((size_t)k * W + i) * vs + a] = m.nlc[((size_t)k * W + slot) * cp + id];
+  const int row = blockIdx.y, ncl = 10 * P.W;
+  if (row < ncl) {
+    const int k = row / P.W, i = row - k * P.W;
+    f.cl[((size_t)k * W + i) * vs + a] = m.nlc[((size_t)k * W + P.mp[i]) * cp + id];
+  } else {
+    const int r = row - ncl;
+    if (r < 10) f.fix[(size_t)r * vs + a] = m.nfix[(size_t)r * cp + id];
+    else if (r < 20) f.pcr[(size_t)(r - 10) * vs + a] = m.nadd[(size_t)(r - 10) * cp + id];
+    else if (r == 20) f.coe[a] = 1.0;   // VM:1619
+    else if (r < 24) f.eigval[(size_t)(r - 21) * vs + a] = m.neval[(size_t)(r - 21) * cp + id];
+    else f.eigvec[(size_t)(r - 24) * vs + a] = m.nevec[(size_t)(r - 24) * cp + id];
   }
-  for (int k = 0; k < 10; k++) { f.fix[(size_t)k * vs + a] = m.nfix[(size_t)k * cp + id]; f.pcr[(size_t)k * vs + a] = m.nadd[(size_t)k * cp + id]; }
-  f.coe[a] = 1.0;   // VM:1619
-  for (int k = 0; k < 3; k++) f.eigval[(size_t)k * vs + a] = m.neval[(size_t)k * cp + id];
-  for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + a] = m.nevec[(size_t)k * cp + id];
 }
 
 // ------------------------------------------------------------------------------------------------ K5: marginalise
@@ -1204,7 +1210,7 @@ inline int map_extract_factors(MapStore &s, hipStream_t st, FactorView f, std::s
   if (!s.allocated) return VBA_OK;
   const MapParams P = map_params(s);
   const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
-  if (nn > 0) hipLaunchKernelGGL(k_extract_write, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, P, f, s.h_cnt[CNT_N]);
+  if (nn > 0) hipLaunchKernelGGL(k_extract_write, dim3((nn + 255) / 256, 10 * s.opt.win_size + 33), dim3(256), 0, st, s.v, P, f, s.h_cnt[CNT_N]);
   MAPCHK(hipGetLastError());
   *n_factors = s.h_cnt[CNT_FACTORS];
   return VBA_OK;
