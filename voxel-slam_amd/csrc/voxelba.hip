@@ -97,7 +97,7 @@ struct vba_ctx {
 
 namespace {
 
-const int kMaxBlocksHess = 256;
+static const int kMaxBlocksHess = getenv("VBA_K3_BLOCKS") ? atoi(getenv("VBA_K3_BLOCKS")) : 256;   // persistent workgroups of the Hessian pass (tuning knob)
 
 int nout_of(int W) { return 36 * W * W + 6 * W + 1; }   // full layout [H | g | r]
 int nout_tl(int W) {                                      // tile layout produced by k_hessian2 (HessCfg2<W>::NOUT2)
