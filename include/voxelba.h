@@ -213,8 +213,10 @@ int vba_odom_lio_state_estimation(vba_ctx *ctx, int n, const double *pnt_body, c
                                   double *cov, int *ok);
 
 /* ------------------------------------------------------------------------------------------------
- * Hierarchical global BA ("next #3"), one keyframe window per call; wdsize must equal the context's
- * win_size (windows of 10 keyframes, VS:3033; larger top-level windows are not supported yet).
+ * Hierarchical global BA ("next #3"), one keyframe window per call.  vba_hba_add_edge accepts any
+ * wdsize >= 2: a window of the context's win_size (the bottom layers use 10, VS:3033) runs on the templated device
+ * kernels; any other size — the top-level BA over all submaps, VS:3103-3113 — takes the sparse path (hashed per-keyframe
+ * clusters, atomics Hessian, LM loop and dense LDL^T on the host).  vba_gba_build requires wdsize == win_size.
  * Keyframe clouds are passed ragged: pnt_local [offsets[wdsize]][3] holds keyframe i's points (its own frame, PCL float
  * values in doubles) in rows offsets[i]..offsets[i+1]; HOST or DEVICE memory.  gba_eigen_value_array is ALREADY INVERTED
  * (VS:3022-3024).

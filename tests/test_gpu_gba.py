@@ -51,6 +51,36 @@ def test_gba_build_parity(oracle, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("W,max_iter", [(24, 2), (40, 1), (3, 2)])
+def test_hba_add_edge_any_window_size(oracle, W, max_iter):
+    """The top layer of the hierarchical BA optimises all submaps at once (VS:3103-3113): windows of any size go through the
+    sparse path (hashed (node, frame) clusters, CSR factor store, atomics Hessian, host LDL^T)."""
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="room_w%d" % W, win_size=W, n_pts=4000)
+    s = synth.make_scans(wl)
+    clouds = [p.astype(np.float32).astype(np.float64) for p in s["points"]]
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    ctx = capi.Context(capi.options_from_workload(synth.CONFIGS["hesai200k_w10"]))     # a context built for W = 10
+    o = ctx.opt
+    cfg = oracle.gba_cfg13(GBA["gba_voxel_size"], GBA["gba_min_eigen_value"], GBA["gba_eig"], o.voxel_size, o.min_eigen_value,
+                           list(o.plane_eigen_value_thre), o.max_layer)
+    got = ctx.hba_add_edge(clouds, poses, GBA["gba_voxel_size"], GBA["gba_min_eigen_value"], GBA["gba_eig"], max_iter, 5)
+    want = oracle.hba_add_edge(clouds, poses, cfg, max_iter, 5)
+    assert want["status"] == 0 and len(got["resis"]) == len(want["resis"])
+    np.testing.assert_allclose(got["resis"], want["resis"], rtol=1e-6)
+    np.testing.assert_allclose(got["poses"], want["poses"], rtol=0, atol=1e-6)
+    ge, we = got["edges"], want["edges"]
+    assert len(ge) == len(we) and len(ge) > 0
+    np.testing.assert_array_equal(ge[:, :2], we[:, :2])
+    np.testing.assert_allclose(ge[:, 2:14], we[:, 2:14], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ge[:, 14:], we[:, 14:], rtol=1e-5)
+    n = sum(len(c) for c in clouds)
+    assert got["cloud_count"].sum() == n
+    assert abs(len(got["cloud"]) - len(want["cloud"])) <= max(3, len(want["cloud"]) // 500)
+    ctx.close()
+
+
 def test_gba_build_other_window_size_is_refused(oracle):
     from voxel_slam_amd import capi
     wl, s, clouds, poses, ctx = _setup("room20k_w4")

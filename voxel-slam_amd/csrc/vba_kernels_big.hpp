@@ -1,0 +1,456 @@
+// Arbitrary window size (W > 16, or any W different from the context's templated window): the top layer of the
+// hierarchical global BA optimises ALL submaps at once (voxelslam.cpp:3103-3113: HBA_add_edge over gba_submaps), so the
+// (voxel, frame) occupancy is sparse and the dense per-voxel [W][10] record of the local-BA path does not apply.
+//   * octree build: as vba_kernels_gba.hpp, but the per-keyframe body clusters live in a hash table keyed (node, frame);
+//   * factor store: CSR over voxels, one entry per occupied (voxel, frame);
+//   * residual pass: one thread per voxel over its entries (evaluate_only_residual, VM:285-325);
+//   * Hessian pass (acc_evaluate2, VM:167-281) in the rank-3 form of k_hessian2: k_big_slot computes every entry's three
+//     6-vectors (g1, g2, h) and adds its diagonal-block remainder E and its gradient, k_big_pairs adds
+//     c1 g1_i g1_j^T + c2 g2_i g2_j^T + c3 h_i h_j^T for every pair of entries of a voxel — f64 atomics into the dense
+//     (6W)^2 matrix (no tiling / MFMA SYRK yet: this path is about capability, the reference runs it rarely);
+//   * the LM loop and the dense (6W)^2 LDL^T run on the host (vba_hostmath.hpp), as does the edge extraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace vba {
+
+struct BigView {
+  int W, V, E, capV, capE;
+  int *vptr;        // [V + 1]
+  int *efr, *evox;  // [E] frame / voxel of an entry
+  double *ecl;      // [10][capE] body clusters
+  double *gv;       // [18][capE] g1, g2, h of an entry (Hessian pass scratch)
+  double *eval, *evec, *pcr;   // [3][capV], [9][capV], [10][capV]
+  double *poses;    // [W][12]
+  double *H, *g, *r;   // dense (6W)^2, 6W, 1
+};
+
+__device__ __forceinline__ void big_cluster_tf(const double *c, const double *R, double *o) { cluster_transform_dev(c, R, o); }
+
+// evaluate_only_residual (VM:285-325) on the sparse store; residual accumulated with one atomic per workgroup
+__global__ __launch_bounds__(256) void k_big_residual(BigView b) {
+  __shared__ double part[4];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  double r = 0.0;
+  if (v < b.V) {
+    const size_t ce = (size_t)b.capE, cv = (size_t)b.capV;
+    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = b.vptr[v]; e < b.vptr[v + 1]; e++) {
+      double c[10], t[10];
+      for (int k = 0; k < 10; k++) c[k] = b.ecl[(size_t)k * ce + e];
+      big_cluster_tf(c, b.poses + 12 * b.efr[e], t);
+      for (int k = 0; k < 10; k++) s[k] += t[k];
+    }
+    const double N = s[9], b0 = s[6] / N, b1 = s[7] / N, b2 = s[8] / N;
+    double w0, w1, w2, U[9];
+    eig3_sym_dev(s[0] / N - b0 * b0, s[1] / N - b1 * b0, s[2] / N - b2 * b0, s[3] / N - b1 * b1, s[4] / N - b2 * b1, s[5] / N - b2 * b2, w0, w1, w2, U);
+    b.eval[v] = w0; b.eval[cv + v] = w1; b.eval[2 * cv + v] = w2;
+    for (int k = 0; k < 9; k++) b.evec[(size_t)k * cv + v] = U[k];
+    for (int k = 0; k < 10; k++) b.pcr[(size_t)k * cv + v] = s[k];
+    r = w0;                                   // coeffs = 1 (LR:380)
+  }
+  r = wave_sum(r);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(b.r, part[0] + part[1] + part[2] + part[3]);
+}
+
+// Hessian pass, part 1: one thread per entry.  Same per-slot algebra as phase A of k_hessian2 (vba_kernels_factor.hpp).
+__global__ void k_big_slot(BigView b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= b.E) return;
+  const size_t ce = (size_t)b.capE, cv = (size_t)b.capV;
+  const int v = b.evox[e], fi = b.efr[e], n6 = 6 * b.W;
+  const double l0 = b.eval[v], l1 = b.eval[cv + v], l2 = b.eval[2 * cv + v];
+  const double NN = b.pcr[9 * cv + v];
+  if (e == b.vptr[v]) unsafeAtomicAdd(b.r, l0);                               // VM:275
+  const double n = b.ecl[9 * ce + e];
+  const double pxx = b.ecl[e], pxy = b.ecl[ce + e], pxz = b.ecl[2 * ce + e], pyy = b.ecl[3 * ce + e], pyz = b.ecl[4 * ce + e], pzz = b.ecl[5 * ce + e];
+  const double vx = b.ecl[6 * ce + e], vy = b.ecl[7 * ce + e], vz = b.ecl[8 * ce + e];
+  const double u00 = b.evec[v], u01 = b.evec[cv + v], u02 = b.evec[2 * cv + v], u10 = b.evec[3 * cv + v], u11 = b.evec[4 * cv + v], u12 = b.evec[5 * cv + v],
+               u20 = b.evec[6 * cv + v], u21 = b.evec[7 * cv + v], u22 = b.evec[8 * cv + v];
+  const double inn = 1.0 / NN;
+  const double bx = b.pcr[6 * cv + v] * inn, by = b.pcr[7 * cv + v] * inn, bz = b.pcr[8 * cv + v] * inn;          // vBar (VM:190)
+  const double *R = b.poses + 12 * fi;
+  const double k0 = u00, k1 = u10, k2 = u20;
+  const double a00 = R[0] * k0 + R[3] * k1 + R[6] * k2, a01 = R[1] * k0 + R[4] * k1 + R[7] * k2, a02 = R[2] * k0 + R[5] * k1 + R[8] * k2;
+  const double a10 = R[0] * u01 + R[3] * u11 + R[6] * u21, a11 = R[1] * u01 + R[4] * u11 + R[7] * u21, a12 = R[2] * u01 + R[5] * u11 + R[8] * u21;
+  const double a20 = R[0] * u02 + R[3] * u12 + R[6] * u22, a21 = R[1] * u02 + R[4] * u12 + R[7] * u22, a22 = R[2] * u02 + R[5] * u12 + R[8] * u22;
+  const double tx = R[9] - bx, ty = R[10] - by, tz = R[11] - bz;                                                   // VM:224
+  const double s0 = k0 * tx + k1 * ty + k2 * tz, s1 = u01 * tx + u11 * ty + u21 * tz, s2 = u02 * tx + u12 * ty + u22 * tz;
+  const double pa00 = pxx * a00 + pxy * a01 + pxz * a02, pa01 = pxy * a00 + pyy * a01 + pyz * a02, pa02 = pxz * a00 + pyz * a01 + pzz * a02;
+  const double pa10 = pxx * a10 + pxy * a11 + pxz * a12, pa11 = pxy * a10 + pyy * a11 + pyz * a12, pa12 = pxz * a10 + pyz * a11 + pzz * a12;
+  const double pa20 = pxx * a20 + pxy * a21 + pxz * a22, pa21 = pxy * a20 + pyy * a21 + pyz * a22, pa22 = pxz * a20 + pyz * a21 + pzz * a22;
+  const double wx = pa00 + s0 * vx, wy = pa01 + s0 * vy, wz = pa02 + s0 * vz;                                      // combo1 = hat(w) VM:228
+  const double c2x = R[0] * vx + R[1] * vy + R[2] * vz + n * tx;                                                   // combo2 VM:229
+  const double c2y = R[3] * vx + R[4] * vy + R[5] * vz + n * ty;
+  const double c2z = R[6] * vx + R[7] * vy + R[8] * vz + n * tz;
+  const double qx = vy * a02 - vz * a01, qy = vz * a00 - vx * a02, qz = vx * a01 - vy * a00;                      // viRiTuk VM:221
+  const double d0 = c2x * k0 + c2y * k1 + c2z * k2;
+  const double d1 = c2x * u01 + c2y * u11 + c2z * u21;
+  const double d2 = c2x * u02 + c2y * u12 + c2z * u22;
+  double gj[6];
+  gj[0] = 2.0 * (wy * a02 - wz * a01) * inn; gj[1] = 2.0 * (wz * a00 - wx * a02) * inn; gj[2] = 2.0 * (wx * a01 - wy * a00) * inn;
+  gj[3] = 2.0 * d0 * k0 * inn; gj[4] = 2.0 * d0 * k1 * inn; gj[5] = 2.0 * d0 * k2 * inn;                          // VM:235-236
+  for (int k = 0; k < 6; k++) unsafeAtomicAdd(b.g + 6 * fi + k, gj[k]);
+  double g1[6], g2[6], hh[6];
+  {
+    const double bx1 = pa10 + s1 * vx, by1 = pa11 + s1 * vy, bz1 = pa12 + s1 * vz;
+    g1[0] = (-(a01 * bz1 - a02 * by1) + (wy * a12 - wz * a11)) * inn;
+    g1[1] = (-(a02 * bx1 - a00 * bz1) + (wz * a10 - wx * a12)) * inn;
+    g1[2] = (-(a00 * by1 - a01 * bx1) + (wx * a11 - wy * a10)) * inn;
+    g1[3] = (k0 * d1 + d0 * u01) * inn; g1[4] = (k1 * d1 + d0 * u11) * inn; g1[5] = (k2 * d1 + d0 * u21) * inn;
+    const double bx2 = pa20 + s2 * vx, by2 = pa21 + s2 * vy, bz2 = pa22 + s2 * vz;
+    g2[0] = (-(a01 * bz2 - a02 * by2) + (wy * a22 - wz * a21)) * inn;
+    g2[1] = (-(a02 * bx2 - a00 * bz2) + (wz * a20 - wx * a22)) * inn;
+    g2[2] = (-(a00 * by2 - a01 * bx2) + (wx * a21 - wy * a20)) * inn;
+    g2[3] = (k0 * d2 + d0 * u02) * inn; g2[4] = (k1 * d2 + d0 * u12) * inn; g2[5] = (k2 * d2 + d0 * u22) * inn;
+  }
+  hh[0] = qx; hh[1] = qy; hh[2] = qz; hh[3] = n * k0; hh[4] = n * k1; hh[5] = n * k2;
+  for (int d = 0; d < 6; d++) { b.gv[(size_t)d * ce + e] = g1[d]; b.gv[(size_t)(6 + d) * ce + e] = g2[d]; b.gv[(size_t)(12 + d) * ce + e] = hh[d]; }
+  // diagonal-block remainder E (VM:242-248; only the symmetric part of the rot-rot block survives)
+  const double wa = wx * a00 + wy * a01 + wz * a02;
+  const double t00 = a01 * pxz - a02 * pxy, t10 = a02 * pxx - a00 * pxz, t20 = a00 * pxy - a01 * pxx;
+  const double t01 = a01 * pyz - a02 * pyy, t11 = a02 * pxy - a00 * pyz, t21 = a00 * pyy - a01 * pxy;
+  const double t02 = a01 * pzz - a02 * pyz, t12 = a02 * pxz - a00 * pzz, t22 = a00 * pyz - a01 * pxz;
+  const double S00 = t01 * a02 - t02 * a01, S01 = -t00 * a02 + t02 * a00, S02 = t00 * a01 - t01 * a00;
+  const double S11 = -t10 * a02 + t12 * a00, S12 = t10 * a01 - t11 * a00;
+  const double S22 = t20 * a01 - t21 * a00;
+  const double e2 = 2.0 * inn;
+  double Eb[6][6];
+  Eb[0][0] = e2 * (a00 * wx - wa - S00); Eb[0][1] = e2 * (0.5 * (a00 * wy + wx * a01) - S01); Eb[0][2] = e2 * (0.5 * (a00 * wz + wx * a02) - S02);
+  Eb[1][1] = e2 * (a01 * wy - wa - S11); Eb[1][2] = e2 * (0.5 * (a01 * wz + wy * a02) - S12); Eb[2][2] = e2 * (a02 * wz - wa - S22);
+  Eb[1][0] = Eb[0][1]; Eb[2][0] = Eb[0][2]; Eb[2][1] = Eb[1][2];
+  const double qq[3] = {qx, qy, qz}, kk[3] = {k0, k1, k2};
+  for (int a = 0; a < 3; a++)
+    for (int c = 0; c < 3; c++) { Eb[a][3 + c] = e2 * qq[a] * kk[c]; Eb[3 + c][a] = Eb[a][3 + c]; Eb[3 + a][3 + c] = e2 * n * kk[a] * kk[c]; }
+  double *Hd = b.H + (size_t)(6 * fi) * n6 + 6 * fi;
+  for (int a = 0; a < 6; a++)
+    for (int c = 0; c < 6; c++) unsafeAtomicAdd(Hd + (size_t)a * n6 + c, Eb[a][c]);
+}
+
+// Hessian pass, part 2: entry i against every entry j of its voxel
+__global__ void k_big_pairs(BigView b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= b.E) return;
+  const size_t ce = (size_t)b.capE, cv = (size_t)b.capV;
+  const int v = b.evox[e], fi = b.efr[e], n6 = 6 * b.W;
+  const double l0 = b.eval[v], l1 = b.eval[cv + v], l2 = b.eval[2 * cv + v], NN = b.pcr[9 * cv + v];
+  const double c1 = 2.0 / (l0 - l1), c2 = 2.0 / (l0 - l2), c3 = -2.0 / NN / NN;                                    // VM:201, 264-268
+  double a1[6], a2[6], a3[6];
+  for (int d = 0; d < 6; d++) { a1[d] = c1 * b.gv[(size_t)d * ce + e]; a2[d] = c2 * b.gv[(size_t)(6 + d) * ce + e]; a3[d] = c3 * b.gv[(size_t)(12 + d) * ce + e]; }
+  for (int j = b.vptr[v]; j < b.vptr[v + 1]; j++) {
+    const int fj = b.efr[j];
+    double b1[6], b2[6], b3[6];
+    for (int d = 0; d < 6; d++) { b1[d] = b.gv[(size_t)d * ce + j]; b2[d] = b.gv[(size_t)(6 + d) * ce + j]; b3[d] = b.gv[(size_t)(12 + d) * ce + j]; }
+    double *Hb = b.H + (size_t)(6 * fi) * n6 + 6 * fj;
+    for (int a = 0; a < 6; a++)
+      for (int c = 0; c < 6; c++) unsafeAtomicAdd(Hb + (size_t)a * n6 + c, a1[a] * b1[c] + a2[a] * b2[c] + a3[a] * b3[c]);
+  }
+}
+
+// ---------------------------------------------------------------- octree build with (node, frame) hashed body clusters
+struct GbaBigView {
+  // roots
+  unsigned long long *hkeys; int *hvals; unsigned int hmask;
+  // nodes
+  int cap, W, npts;
+  double *nadd, *ncenter, *neval, *nevec;
+  float *nql;
+  int *nchild, *nfac, *nexi;
+  signed char *nlayer;
+  // (node, frame) entries
+  unsigned long long *ekeys; unsigned int emask; double *ecl;   // [10][emask + 1]
+  // points
+  double *pw; const double *pl; int *pframe, *pnode;
+  int *cnt; double *poses; int *offsets;
+};
+
+__device__ __forceinline__ int big_frame_of(const int *offsets, int W, int p) {   // largest f with offsets[f] <= p
+  int lo = 0, hi = W;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
+
+__global__ void k_gbab_keys(GbaBigView g, GbaParams P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.npts) return;
+  const int f = big_frame_of(g.offsets, g.W, p);
+  const double *R = g.poses + 12 * (size_t)f;
+  const double x = g.pl[3 * (size_t)p], y = g.pl[3 * (size_t)p + 1], z = g.pl[3 * (size_t)p + 2];
+  const double wx = (R[0] * x + R[1] * y + R[2] * z) + R[9], wy = (R[3] * x + R[4] * y + R[5] * z) + R[10], wz = (R[6] * x + R[7] * y + R[8] * z) + R[11];
+  const size_t n = (size_t)g.npts;
+  g.pw[p] = wx; g.pw[n + p] = wy; g.pw[2 * n + p] = wz;
+  g.pframe[p] = f;
+  const long long kx = key_axis(wx, P.voxel_size), ky = key_axis(wy, P.voxel_size), kz = key_axis(wz, P.voxel_size);
+  if (kx < -KEY_OFF || kx >= KEY_OFF || ky < -KEY_OFF || ky >= KEY_OFF || kz < -KEY_OFF || kz >= KEY_OFF) { g.pnode[p] = -1; atomicExch(&g.cnt[GCNT_OVERFLOW], 2); return; }
+  const unsigned long long key = pack_key(kx, ky, kz);
+  unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & g.hmask;
+  for (unsigned int probe = 0; probe <= g.hmask; probe++) {
+    const unsigned long long old = atomicCAS(&g.hkeys[h], KEY_EMPTY, key);
+    if (old == KEY_EMPTY || old == key) break;
+    h = (h + 1) & g.hmask;
+  }
+  g.pnode[p] = (int)h;
+}
+__global__ void k_gbab_roots(GbaBigView g, GbaParams P) {
+  const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > g.hmask) return;
+  const unsigned long long key = g.hkeys[s];
+  if (key == KEY_EMPTY) return;
+  const int id = atomicAdd(&g.cnt[GCNT_NODES], 1);
+  if (id >= g.cap) { atomicExch(&g.cnt[GCNT_OVERFLOW], 1); g.hvals[s] = -1; return; }
+  g.hvals[s] = id;
+  long long kx, ky, kz;
+  unpack_key(key, kx, ky, kz);
+  const size_t cp = (size_t)g.cap;
+  g.ncenter[id] = (0.5 + (double)kx) * P.voxel_size; g.ncenter[cp + id] = (0.5 + (double)ky) * P.voxel_size; g.ncenter[2 * cp + id] = (0.5 + (double)kz) * P.voxel_size;
+  g.nql[id] = (float)(P.voxel_size / 4.0);
+  g.nlayer[id] = 0; g.nchild[id] = -1; g.nfac[id] = -1;
+}
+__global__ void k_gbab_rootid(GbaBigView g) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.npts) return;
+  const int s = g.pnode[p];
+  if (s >= 0) g.pnode[p] = g.hvals[s];
+}
+__global__ void k_gbab_accum(GbaBigView g) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.npts) return;
+  const int id = g.pnode[p];
+  if (id < 0) return;
+  const size_t n = (size_t)g.npts, cp = (size_t)g.cap, ct = (size_t)g.emask + 1;
+  atomic_cluster_add(g.nadd + id, cp, g.pw[p], g.pw[n + p], g.pw[2 * n + p]);
+  const unsigned long long key = ((unsigned long long)(unsigned int)id << 20) | (unsigned int)g.pframe[p];
+  unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & g.emask;
+  for (unsigned int probe = 0; probe <= g.emask; probe++) {
+    const unsigned long long old = atomicCAS(&g.ekeys[h], KEY_EMPTY, key);
+    if (old == KEY_EMPTY) { atomicAdd(&g.nexi[id], 1); break; }       // a new (node, frame) pair: one more keyframe sees the node
+    if (old == key) break;
+    h = (h + 1) & g.emask;
+  }
+  atomic_cluster_add(g.ecl + h, ct, g.pl[3 * (size_t)p], g.pl[3 * (size_t)p + 1], g.pl[3 * (size_t)p + 2]);
+}
+__global__ void k_gbab_decide(GbaBigView g, GbaParams P, int layer) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = g.cnt[GCNT_NODES] < g.cap ? g.cnt[GCNT_NODES] : g.cap;
+  if (id >= nn || g.nlayer[id] != layer) return;
+  const size_t cp = (size_t)g.cap;
+  const double N = g.nadd[9 * cp + id];
+  if (N <= 10.0) return;                                                               // LR:360
+  const double cx = g.nadd[6 * cp + id] / N, cy = g.nadd[7 * cp + id] / N, cz = g.nadd[8 * cp + id] / N;
+  double w0, w1, w2, V[9];
+  eig3_sym_dev(g.nadd[id] / N - cx * cx, g.nadd[cp + id] / N - cx * cy, g.nadd[2 * cp + id] / N - cx * cz, g.nadd[3 * cp + id] / N - cy * cy,
+               g.nadd[4 * cp + id] / N - cy * cz, g.nadd[5 * cp + id] / N - cz * cz, w0, w1, w2, V);
+  if ((w0 < P.min_eigen_value) && ((w0 / w2) < P.eig_array[layer])) {                  // LR:310-314
+    if (g.nexi[id] <= 1) return;                                                        // LR:371-375
+    if (w0 / w1 > 0.12) return;                                                         // LR:377
+    g.nfac[id] = atomicAdd(&g.cnt[GCNT_FACTORS], 1);
+    g.neval[id] = w0; g.neval[cp + id] = w1; g.neval[2 * cp + id] = w2;
+    for (int k = 0; k < 9; k++) g.nevec[(size_t)k * cp + id] = V[k];
+    return;
+  }
+  if (layer >= P.max_layer) return;
+  const int base = atomicAdd(&g.cnt[GCNT_NODES], 8);
+  if (base + 8 > g.cap) { atomicExch(&g.cnt[GCNT_OVERFLOW], 1); return; }
+  const float ql = g.nql[id];
+  const double c0 = g.ncenter[id], c1 = g.ncenter[cp + id], c2 = g.ncenter[2 * cp + id];
+  for (int o = 0; o < 8; o++) {
+    const int ch = base + o;
+    g.ncenter[ch] = c0 + (double)((float)(2 * ((o >> 2) & 1) - 1) * ql);
+    g.ncenter[cp + ch] = c1 + (double)((float)(2 * ((o >> 1) & 1) - 1) * ql);
+    g.ncenter[2 * cp + ch] = c2 + (double)((float)(2 * (o & 1) - 1) * ql);
+    g.nql[ch] = ql / 2;
+    g.nlayer[ch] = (signed char)(layer + 1); g.nchild[ch] = -1; g.nfac[ch] = -1;
+  }
+  g.nchild[id] = base;
+}
+__global__ void k_gbab_descend(GbaBigView g) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.npts) return;
+  const int id = g.pnode[p];
+  if (id < 0) return;
+  const int base = g.nchild[id];
+  if (base < 0) { g.pnode[p] = -1; return; }
+  const size_t n = (size_t)g.npts, cp = (size_t)g.cap;
+  g.pnode[p] = base + 4 * (g.pw[p] > g.ncenter[id] ? 1 : 0) + 2 * (g.pw[n + p] > g.ncenter[cp + id] ? 1 : 0) + (g.pw[2 * n + p] > g.ncenter[2 * cp + id] ? 1 : 0);
+}
+// planar voxels -> CSR.  vcnt[a] = entries of factor a; after the scan, the table slots are scattered to their rows.
+__global__ void k_gbab_vcount(GbaBigView g, int *vcnt) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = g.cnt[GCNT_NODES] < g.cap ? g.cnt[GCNT_NODES] : g.cap;
+  if (id >= nn) return;
+  const int a = g.nfac[id];
+  if (a >= 0) vcnt[a] = g.nexi[id];
+}
+__global__ __launch_bounds__(256) void k_big_scan(int n, const int *__restrict__ in, int *__restrict__ out /*[n+1]*/) {   // one workgroup, exclusive
+  __shared__ int part[256];
+  const int t = threadIdx.x, per = (n + 255) / 256;
+  int s = 0;
+  for (int k = 0; k < per; k++) { const int i = t * per + k; if (i < n) s += in[i]; }
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 256; k++) { const int v = part[k]; part[k] = acc; acc += v; } out[n] = acc; }
+  __syncthreads();
+  int acc = part[t];
+  for (int k = 0; k < per; k++) { const int i = t * per + k; if (i < n) { out[i] = acc; acc += in[i]; } }
+}
+__global__ void k_gbab_fill(GbaBigView g, BigView b, int *fill) {
+  const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > g.emask) return;
+  const unsigned long long key = g.ekeys[s];
+  if (key == KEY_EMPTY) return;
+  const int id = (int)(key >> 20), fr = (int)(key & 0xFFFFF);
+  const int a = g.nfac[id];
+  if (a < 0) return;
+  const int pos = b.vptr[a] + atomicAdd(&fill[a], 1);
+  const size_t ct = (size_t)g.emask + 1, ce = (size_t)b.capE;
+  b.efr[pos] = fr; b.evox[pos] = a;
+  for (int k = 0; k < 10; k++) b.ecl[(size_t)k * ce + pos] = g.ecl[(size_t)k * ct + s];
+}
+__global__ void k_gbab_voxels(GbaBigView g, BigView b) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = g.cnt[GCNT_NODES] < g.cap ? g.cnt[GCNT_NODES] : g.cap;
+  if (id >= nn) return;
+  const int a = g.nfac[id];
+  if (a < 0) return;
+  const size_t cp = (size_t)g.cap, cv = (size_t)b.capV;
+  for (int k = 0; k < 3; k++) b.eval[(size_t)k * cv + a] = g.neval[(size_t)k * cp + id];
+  for (int k = 0; k < 9; k++) b.evec[(size_t)k * cv + a] = g.nevec[(size_t)k * cp + id];
+  for (int k = 0; k < 10; k++) b.pcr[(size_t)k * cv + a] = g.nadd[(size_t)k * cp + id];
+}
+
+// ---------------------------------------------------------------- host side
+struct BigStore {
+  BigView b{};
+  GbaBigView g{};
+  std::vector<void *> bufs;
+  int *h_cnt = nullptr;
+  int *d_vcnt = nullptr, *d_fill = nullptr;
+  void release() { for (void *p : bufs) hipFree(p); bufs.clear(); if (h_cnt) hipHostFree(h_cnt); h_cnt = nullptr; b = BigView(); g = GbaBigView(); }
+};
+
+#define BIGCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return VBA_ERR_HIP; } } while (0)
+
+// Builds the octree of `W` keyframes and the sparse factor store (everything is re-allocated per call: the top-level BA
+// runs once per loop closure).  pl: device pointer to the local points [n][3].
+inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, const double *d_pl, const double *poses, const GbaParams &P, std::string &err) {
+  s.release();
+  const int n = offsets[W];
+  auto al = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) s.bufs.push_back(*p); return e; };
+  BIGCHK(hipHostMalloc((void **)&s.h_cnt, GCNT_N * sizeof(int), hipHostMallocDefault));
+  GbaBigView &g = s.g;
+  g.W = W; g.npts = n; g.pl = d_pl;
+  unsigned int hcap = 1u << 16; while (hcap < 2u * (unsigned)n && hcap < (1u << 28)) hcap <<= 1;
+  unsigned int ecap = 1u << 16;                         // (node, frame) pairs of ALL levels share the table: <= points per level
+  while ((unsigned long long)ecap < 2ull * (unsigned long long)n * (unsigned)(P.max_layer + 1) && ecap < (1u << 30)) ecap <<= 1;
+  g.hmask = hcap - 1; g.emask = ecap - 1;
+  BIGCHK(al((void **)&g.hkeys, (size_t)hcap * 8)); BIGCHK(al((void **)&g.hvals, (size_t)hcap * 4));
+  BIGCHK(al((void **)&g.ekeys, (size_t)ecap * 8)); BIGCHK(al((void **)&g.ecl, (size_t)ecap * 10 * 8));
+  BIGCHK(al((void **)&g.pw, (size_t)n * 3 * 8)); BIGCHK(al((void **)&g.pframe, (size_t)n * 4)); BIGCHK(al((void **)&g.pnode, (size_t)n * 4));
+  BIGCHK(al((void **)&g.cnt, GCNT_N * sizeof(int))); BIGCHK(al((void **)&g.poses, (size_t)W * 12 * 8)); BIGCHK(al((void **)&g.offsets, (size_t)(W + 1) * 4));
+  BIGCHK(hipMemcpyAsync(g.poses, poses, (size_t)W * 12 * 8, hipMemcpyHostToDevice, st));
+  BIGCHK(hipMemcpyAsync(g.offsets, offsets, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+  int cap = 1 << 17;
+  const dim3 bk(256), gp((n + 255) / 256);
+  for (int attempt = 0; attempt < 10; attempt++) {
+    const size_t cp = (size_t)cap;
+    g.cap = cap;
+    void *tmp[9];
+    size_t sz[9] = {10 * cp * 8, 3 * cp * 8, 3 * cp * 8, 9 * cp * 8, cp * 4, cp * 4, cp * 4, cp * 4, cp};
+    for (int k = 0; k < 9; k++) { if (hipMalloc(&tmp[k], sz[k]) != hipSuccess) { err = "octree node storage"; return VBA_ERR_HIP; } }
+    g.nadd = (double *)tmp[0]; g.ncenter = (double *)tmp[1]; g.neval = (double *)tmp[2]; g.nevec = (double *)tmp[3]; g.nql = (float *)tmp[4];
+    g.nchild = (int *)tmp[5]; g.nfac = (int *)tmp[6]; g.nexi = (int *)tmp[7]; g.nlayer = (signed char *)tmp[8];
+    BIGCHK(hipMemsetAsync(g.cnt, 0, GCNT_N * sizeof(int), st));
+    BIGCHK(hipMemsetAsync(g.hkeys, 0xFF, (size_t)hcap * 8, st));
+    BIGCHK(hipMemsetAsync(g.nadd, 0, 10 * cp * 8, st));
+    BIGCHK(hipMemsetAsync(g.nexi, 0, cp * 4, st));
+    if (n > 0) {
+      hipLaunchKernelGGL(k_gbab_keys, gp, bk, 0, st, g, P);
+      hipLaunchKernelGGL(k_gbab_roots, dim3((hcap + 255) / 256), bk, 0, st, g, P);
+      hipLaunchKernelGGL(k_gbab_rootid, gp, bk, 0, st, g);
+      for (int L = 0; L <= P.max_layer; L++) {
+        // entries of the previous level are dead: a planar node keeps its own entries (it stopped descending), so the
+        // table is only cleared of nothing here — finished nodes never receive points again and their keys stay valid
+        if (L == 0) { BIGCHK(hipMemsetAsync(g.ekeys, 0xFF, (size_t)ecap * 8, st)); BIGCHK(hipMemsetAsync(g.ecl, 0, (size_t)ecap * 10 * 8, st)); }
+        hipLaunchKernelGGL(k_gbab_accum, gp, bk, 0, st, g);
+        hipLaunchKernelGGL(k_gbab_decide, dim3((cap + 255) / 256), bk, 0, st, g, P, L);
+        if (L < P.max_layer) hipLaunchKernelGGL(k_gbab_descend, gp, bk, 0, st, g);
+      }
+    }
+    BIGCHK(hipGetLastError());
+    BIGCHK(hipStreamSynchronize(st));
+    BIGCHK(hipMemcpyAsync(s.h_cnt, g.cnt, GCNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
+    BIGCHK(hipStreamSynchronize(st));
+    if (s.h_cnt[GCNT_OVERFLOW] == 2) { for (int k = 0; k < 9; k++) hipFree(tmp[k]); err = "keyframe point outside the 21-bit voxel index range"; return VBA_ERR_CAPACITY; }
+    if (!s.h_cnt[GCNT_OVERFLOW]) { for (int k = 0; k < 9; k++) s.bufs.push_back(tmp[k]); break; }
+    for (int k = 0; k < 9; k++) hipFree(tmp[k]);
+    cap *= 2;
+    if (attempt == 9) { err = "octree node capacity"; return VBA_ERR_CAPACITY; }
+  }
+  // sparse factor store
+  BigView &b = s.b;
+  const int V = s.h_cnt[GCNT_FACTORS];
+  b.W = W; b.V = V; b.capV = V > 0 ? V : 1;
+  BIGCHK(al((void **)&b.vptr, (size_t)(V + 1) * 4)); BIGCHK(al((void **)&s.d_vcnt, (size_t)b.capV * 4)); BIGCHK(al((void **)&s.d_fill, (size_t)b.capV * 4));
+  BIGCHK(al((void **)&b.eval, (size_t)b.capV * 3 * 8)); BIGCHK(al((void **)&b.evec, (size_t)b.capV * 9 * 8)); BIGCHK(al((void **)&b.pcr, (size_t)b.capV * 10 * 8));
+  BIGCHK(al((void **)&b.poses, (size_t)W * 12 * 8));
+  const size_t n6 = (size_t)6 * W;
+  BIGCHK(al((void **)&b.H, n6 * n6 * 8)); BIGCHK(al((void **)&b.g, n6 * 8)); BIGCHK(al((void **)&b.r, 8));
+  BIGCHK(hipMemsetAsync(s.d_fill, 0, (size_t)b.capV * 4, st));
+  BIGCHK(hipMemsetAsync(b.vptr, 0, (size_t)(V + 1) * 4, st));
+  int E = 0;
+  if (V > 0) {
+    const int nn = s.h_cnt[GCNT_NODES] < g.cap ? s.h_cnt[GCNT_NODES] : g.cap;
+    hipLaunchKernelGGL(k_gbab_vcount, dim3((nn + 255) / 256), bk, 0, st, g, s.d_vcnt);
+    hipLaunchKernelGGL(k_big_scan, dim3(1), bk, 0, st, V, s.d_vcnt, b.vptr);
+    BIGCHK(hipStreamSynchronize(st));
+    BIGCHK(hipMemcpyAsync(&E, b.vptr + V, 4, hipMemcpyDeviceToHost, st));
+    BIGCHK(hipStreamSynchronize(st));
+  }
+  b.E = E; b.capE = E > 0 ? E : 1;
+  BIGCHK(al((void **)&b.efr, (size_t)b.capE * 4)); BIGCHK(al((void **)&b.evox, (size_t)b.capE * 4));
+  BIGCHK(al((void **)&b.ecl, (size_t)b.capE * 10 * 8)); BIGCHK(al((void **)&b.gv, (size_t)b.capE * 18 * 8));
+  if (V > 0) {
+    const int nn = s.h_cnt[GCNT_NODES] < g.cap ? s.h_cnt[GCNT_NODES] : g.cap;
+    hipLaunchKernelGGL(k_gbab_fill, dim3((ecap + 255) / 256), bk, 0, st, g, b, s.d_fill);
+    hipLaunchKernelGGL(k_gbab_voxels, dim3((nn + 255) / 256), bk, 0, st, g, b);
+    BIGCHK(hipGetLastError());
+  }
+  return VBA_OK;
+}
+
+// divide_thread (VM:347-389): H, g, r at `poses` on the host side buffers (full layout)
+inline int big_hessian(BigStore &s, hipStream_t st, const double *poses, double *H, double *gvec, double *r, std::string &err) {
+  BigView &b = s.b;
+  const size_t n6 = (size_t)6 * b.W;
+  BIGCHK(hipMemcpyAsync(b.poses, poses, (size_t)b.W * 12 * 8, hipMemcpyHostToDevice, st));
+  BIGCHK(hipMemsetAsync(b.H, 0, n6 * n6 * 8, st)); BIGCHK(hipMemsetAsync(b.g, 0, n6 * 8, st)); BIGCHK(hipMemsetAsync(b.r, 0, 8, st));
+  if (b.E > 0) {
+    hipLaunchKernelGGL(k_big_slot, dim3((b.E + 127) / 128), dim3(128), 0, st, b);
+    hipLaunchKernelGGL(k_big_pairs, dim3((b.E + 127) / 128), dim3(128), 0, st, b);
+    BIGCHK(hipGetLastError());
+  }
+  BIGCHK(hipStreamSynchronize(st));
+  BIGCHK(hipMemcpyAsync(H, b.H, n6 * n6 * 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipMemcpyAsync(gvec, b.g, n6 * 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipMemcpyAsync(r, b.r, 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipStreamSynchronize(st));
+  return VBA_OK;
+}
+// only_residual (VM:391-420): also refreshes the per-voxel eigen state
+inline int big_residual(BigStore &s, hipStream_t st, const double *poses, double *r, std::string &err) {
+  BigView &b = s.b;
+  BIGCHK(hipMemcpyAsync(b.poses, poses, (size_t)b.W * 12 * 8, hipMemcpyHostToDevice, st));
+  BIGCHK(hipMemsetAsync(b.r, 0, 8, st));
+  if (b.V > 0) hipLaunchKernelGGL(k_big_residual, dim3((b.V + 255) / 256), dim3(256), 0, st, b);
+  BIGCHK(hipGetLastError());
+  BIGCHK(hipStreamSynchronize(st));
+  BIGCHK(hipMemcpyAsync(r, b.r, 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipStreamSynchronize(st));
+  return VBA_OK;
+}
+
+}  // namespace vba

@@ -10,6 +10,7 @@
 #include "vba_kernels_li.hpp"
 #include "vba_kernels_scan.hpp"
 #include "vba_kernels_gba.hpp"
+#include "vba_kernels_big.hpp"
 #include <cstddef>
 #include "vba_hostmath.hpp"
 
@@ -89,6 +90,7 @@ struct vba_ctx {
 
   MapStore map;
   GbaStore gba;
+  BigStore big;                   // arbitrary-window path (top-level global BA)
   double *d_refpts = nullptr;     // submap cloud staging (HBA_add_edge)
   size_t refpts_doubles = 0;
 
@@ -426,6 +428,7 @@ void vba_destroy(vba_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   map_free(c->map);
   c->gba.free_all();
+  c->big.release();
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
   if (c->li_fork) hipEventDestroy(c->li_fork);
@@ -1039,10 +1042,73 @@ int vba_gba_build(vba_ctx *c, int wdsize, const int *offsets, const double *pnt_
   return gba_build_into_store(c, wdsize, offsets, pnt_local, poses, gba_params(c, gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array));
 }
 
+// Lidar_BA_Optimizer::damping_iter (VM:422-497) for an arbitrary window: device Hessian / residual passes on the sparse
+// store, gauge + (H + uD) LDL^T + retraction on the host.
+static int big_damping_iter(vba_ctx *c, int W, double *poses, std::vector<double> &hess_out, double *resis2, int max_iter, int thd_num, int *is_converge) {
+  BigStore &S = c->big;
+  const int n = 6 * W;
+  if (S.b.V < thd_num) return VBA_ERR_TOO_FEW_VOXELS;                 // VM:399-403
+  std::vector<double> x(poses, poses + (size_t)W * 12), xt(x), Hess((size_t)n * n), JacT(n), A((size_t)n * n), rhs(n), dxi(n);
+  double u = 0.01, v = 2, residual1 = 0, residual2 = 0;
+  bool is_calc_hess = true, conv = true;
+  c->trace.clear();
+  for (int it = 0; it < max_iter; it++) {
+    if (is_calc_hess) {
+      int st = big_hessian(S, c->stream, x.data(), Hess.data(), JacT.data(), &residual1, c->err);
+      if (st) return st;
+      hess_out = Hess;                                                // *hess = Hess (VM:446)
+    }
+    if (it == 0) resis2[0] = residual1;
+    for (int r = 0; r < 6; r++) for (int k = 0; k < n; k++) { Hess[(size_t)r * n + k] = 0; Hess[(size_t)k * n + r] = 0; }
+    for (int r = 0; r < 6; r++) { Hess[(size_t)r * n + r] = 1; JacT[r] = 0; }
+    A = Hess;
+    for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * Hess[(size_t)r * n + r]; rhs[r] = -JacT[r]; }
+    vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), n);     // VM:458
+    for (int j = 0; j < W; j++) {
+      double E[9];
+      vbh::so3_exp(&dxi[6 * j], E);
+      vbh::m3_mul(&x[12 * j], E, &xt[12 * j]);
+      for (int k = 0; k < 3; k++) xt[12 * j + 9 + k] = x[12 * j + 9 + k] + dxi[6 * j + 3 + k];
+    }
+    double q1 = 0;
+    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * Hess[(size_t)r * n + r] * dxi[r] - JacT[r]);
+    q1 *= 0.5;
+    int st = big_residual(S, c->stream, xt.data(), &residual2, c->err);
+    if (st) return st;
+    double q = residual1 - residual2;
+    const double tr[5] = {residual1, residual2, u, v, q1};
+    c->trace.insert(c->trace.end(), tr, tr + 5);
+    if (q > 0) {
+      x = xt;
+      q = q / q1;
+      v = 2;
+      q = 1 - std::pow(2 * q - 1, 3);
+      u *= (q < 1.0 / 3 ? 1.0 / 3 : q);
+      is_calc_hess = true;
+    } else {
+      u = u * v; v = 2 * v;
+      is_calc_hess = false; conv = false;
+    }
+    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+  }
+  resis2[1] = residual2;
+  std::memcpy(poses, x.data(), x.size() * sizeof(double));
+  if (is_converge) *is_converge = conv ? 1 : 0;
+  return VBA_OK;
+}
+
 int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *pnt_local, double *poses, double gba_voxel_size,
                      double gba_min_eigen_value, const double *gba_eigen_value_array, int max_iter, int thread_num, double *edges_out, int *n_edges,
                      double *cloud_out, int *cloud_count, int *n_cloud, double *resis_log, int *n_log) {
-  int st = gba_check(c, wdsize, offsets, pnt_local, poses);
+  const bool big = (wdsize != c->opt.win_size);      // any other window size (the top-level BA over all submaps): sparse path
+  if (big && wdsize < 2) return VBA_ERR_BAD_ARG;
+  int st = VBA_OK;
+  if (!big) st = gba_check(c, wdsize, offsets, pnt_local, poses);
+  else {
+    if (!offsets || !poses || offsets[0] != 0) return VBA_ERR_BAD_ARG;
+    for (int i = 0; i < wdsize; i++) if (offsets[i + 1] < offsets[i]) return VBA_ERR_BAD_ARG;
+    if (offsets[wdsize] > 0 && !pnt_local) return VBA_ERR_BAD_ARG;
+  }
   if (st) return st;
   if (!gba_eigen_value_array || !edges_out || !n_edges || (cloud_out && (!cloud_count || !n_cloud))) return VBA_ERR_BAD_ARG;
   const int W = wdsize, n6 = 6 * W, n = offsets[W];
@@ -1064,11 +1130,17 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
   for (int iterCnt = 0; iterCnt < max_iter; iterCnt++) {
     if (converge_flag == 1 || iterCnt == max_iter - 1)                    // VS:2871-2881: last pass with the local-map parameters
       P = gba_params(c, c->opt.voxel_size, c->opt.min_eigen_value, c->opt.plane_eigen_value_thre);
-    st = gba_build_into_store(c, W, offsets, d_pl, poses, P);
-    if (st) return st;
     double resis[2] = {0, 0};
     int is_converge = 0;
-    st = vba_lidar_ba_damping_iter(c, poses, hess.data(), resis, up, thread_num, &is_converge);
+    if (!big) {
+      st = gba_build_into_store(c, W, offsets, d_pl, poses, P);
+      if (st) return st;
+      st = vba_lidar_ba_damping_iter(c, poses, hess.data(), resis, up, thread_num, &is_converge);
+    } else {
+      st = big_build(c->big, c->stream, W, offsets, d_pl, poses, P, c->err);
+      if (st) return st;
+      st = big_damping_iter(c, W, poses, hess, resis, up, thread_num, &is_converge);
+    }
     if (st) return st;
     if (resis_log && n_log) { resis_log[2 * *n_log] = resis[0]; resis_log[2 * *n_log + 1] = resis[1]; (*n_log)++; }
     if ((std::fabs(resis[0] - resis[1]) / resis[0] < converge_thre && is_converge) || (iterCnt == max_iter - 2 && converge_flag == 0)) {
@@ -1107,8 +1179,10 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
         const double d[3] = {Ri[9] - R0[9], Ri[10] - R0[10], Ri[11] - R0[11]};
         vbh::m3_Tvec(R0, d, rel.data() + 12 * i + 9);
       }
-      HIPCHK(c, hipMemcpyAsync(c->gba.v.poses, rel.data(), rel.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(k_gba_to_ref, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, W, c->gba.v.offsets, d_pl, c->gba.v.poses, d_ref);
+      double *d_rel = big ? c->big.g.poses : c->gba.v.poses;
+      const int *d_off = big ? c->big.g.offsets : c->gba.v.offsets;
+      HIPCHK(c, hipMemcpyAsync(d_rel, rel.data(), rel.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_gba_to_ref, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, W, d_off, d_pl, d_rel, d_ref);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));      // rel is a host temporary
       std::vector<int> first(n);
