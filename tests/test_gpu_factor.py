@@ -97,7 +97,9 @@ def test_synthetic_scene_factor_parity(capi, oracle, synth, name):
     H, g, r = ctx.acc_evaluate2(poses); H2, g2, r2 = f.acc_evaluate2(poses)
     assert _relerr(H, H2) < 1e-9 and _relerr(g, g2) < 1e-9 and abs(r - r2) < 1e-12 * abs(r2)
     # residual pass rewrites eig / pcr_add on both sides
-    assert abs(ctx.evaluate_only_residual(poses) - f.evaluate_only_residual(poses)) < 1e-12 * abs(r2)
+    # (sum of smallest eigenvalues: each one is known to eps x second moments; the device adds the frames of a voxel in
+    #  quad order, the oracle in frame order)
+    assert abs(ctx.evaluate_only_residual(poses) - f.evaluate_only_residual(poses)) < 1e-11 * abs(r2)
     ev, evec, pa = ctx.read_back(); ev2, evec2, pa2 = f.read_back()
     assert np.allclose(pa, pa2, rtol=1e-12, atol=1e-9)
     # cov = P/N - vBar vBar^T cancels second moments of O(|p|^2) ~ 1e3 m^2: eps * 1e3 bounds the eigenvalue agreement
