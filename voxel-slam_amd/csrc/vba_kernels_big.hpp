@@ -8,7 +8,8 @@
 //     6-vectors (g1, g2, h) and adds its diagonal-block remainder E and its gradient, k_big_pairs adds
 //     c1 g1_i g1_j^T + c2 g2_i g2_j^T + c3 h_i h_j^T for every pair of entries of a voxel — f64 atomics into the dense
 //     (6W)^2 matrix (no tiling / MFMA SYRK yet: this path is about capability, the reference runs it rarely);
-//   * the LM loop and the dense (6W)^2 LDL^T run on the host (vba_hostmath.hpp), as does the edge extraction.
+//   * the dense (6W)^2 LDL^T runs in HBM (k_bigl_*: panel kernel + MFMA trailing update per 8 columns); the LM bookkeeping,
+//     the O(n^2) back substitution and the edge extraction stay on the host.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
@@ -322,6 +323,116 @@ __global__ void k_gbab_voxels(GbaBigView g, BigView b) {
   for (int k = 0; k < 10; k++) b.pcr[(size_t)k * cv + a] = g.nadd[(size_t)k * cp + id];
 }
 
+// ---------------------------------------------------------------- dense LDL^T of the (6W)^2 system in HBM
+// Right-looking, panels of 8 columns, static pivot order (Eigen's "largest |diagonal| first" as a permutation computed by
+// the caller).  Ab = (NP + 1) x ld row-major, lower triangle of P (H + uD) P^T, identity on the padding n..NP-1, row NP =
+// the right-hand side (so D^-1 L^-1 b falls out as that row of L).  Two kernels per panel:
+//   k_bigl_panel   one workgroup: every thread factorises the 8x8 diagonal block in registers (as vba_ldlt.hpp) and
+//                  substitutes the rows it owns; L overwrites the panel in place, -T = -L D goes to Tb[row][8];
+//   k_bigl_update  one workgroup per 64x64 tile of the trailing lower triangle: C -= L (T)^T on the matrix cores
+//                  (v_mfma_f64_16x16x4_f64, two per 16x16 sub-tile, operands staged in LDS).
+__global__ void k_bigl_setup(const double *__restrict__ H, const double *__restrict__ g, const int *__restrict__ ord, int n, int NP, int ld, double u,
+                             double *__restrict__ Ab) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)(NP + 1) * NP;
+  if (t >= tot) return;
+  const int i = (int)(t / NP), j = (int)(t - (long long)i * NP);
+  double a = 0.0;
+  if (j >= n) a = (i == j) ? 1.0 : 0.0;                      // padding columns
+  else if (i == NP) { const int pj = ord[j]; a = (pj < 6) ? 0.0 : -g[pj]; }      // rhs row: -JacT, gauge rows zeroed (VM:455)
+  else if (i >= n || i < j) a = 0.0;
+  else {
+    const int pi = ord[i], pj = ord[j];
+    const int rr = pi > pj ? pi : pj, cc = pi > pj ? pj : pi;
+    a = (rr < 6 || cc < 6) ? ((rr == cc) ? 1.0 : 0.0) : H[(size_t)rr * n + cc];
+    if (i == j) a += u * a;
+  }
+  Ab[(size_t)i * ld + j] = a;
+}
+
+__global__ __launch_bounds__(256) void k_bigl_panel(double *__restrict__ Ab, double *__restrict__ Tb, int NP, int ld, int k0) {
+  double D[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) D[r][c] = Ab[(size_t)(k0 + r) * ld + k0 + c];
+  double dv[8], di[8];
+  bool okv[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const double d = D[c][c];
+    const bool ok = fabs(d) > 0.0;
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, y0, 1.0);
+    const double y1 = fma(e, y0, y0), e2 = e * e;
+    const double inv = fma(e2, y1, y1);
+    const double dinv = ok ? inv : 0.0;
+    dv[c] = d; di[c] = dinv; okv[c] = ok;
+#pragma unroll
+    for (int r = c + 1; r < 8; r++)
+#pragma unroll
+      for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] = fma(-(D[r][c] * D[c2][c]), dinv, D[r][c2]);
+  }
+  // D[r][c] (r > c) now holds the UNSCALED column values (T of the block); L = T / d
+  __syncthreads();                                            // every thread has read the diagonal block before rows are rewritten
+  for (int i = k0 + threadIdx.x; i <= NP; i += 256) {
+    const int ib = i - k0;
+    double x[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) x[c] = Ab[(size_t)i * ld + k0 + c];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      double lv = okv[c] ? x[c] * di[c] : x[c];
+      if (i == NP) lv = (fabs(dv[c]) > 2.2250738585072014e-308) ? x[c] * di[c] : 0.0;
+      lv = (ib > c) ? lv : 0.0;
+      const double tmc = (okv[c] && ib > c) ? x[c] : 0.0;
+      if (ib > c) Ab[(size_t)i * ld + k0 + c] = lv;            // L in place (the diagonal keeps d)
+      Tb[(size_t)i * 8 + c] = -tmc;
+#pragma unroll
+      for (int c2 = c + 1; c2 < 8; c2++) x[c2] = fma(-(tmc * D[c2][c]), di[c], x[c2]);
+    }
+    if (ib < 8) Ab[(size_t)i * ld + k0 + ib] = dv[ib];        // (unchanged value, written for clarity of the layout)
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bigl_update(double *__restrict__ Ab, const double *__restrict__ Tb, int NP, int ld, int k0) {
+  __shared__ double Ls[64][9], Ts[64][9];
+  // tile (ti, tj), ti >= tj, of the trailing block that starts at row / column kn = k0 + 8
+  const int kn = k0 + 8;
+  int tj = 0, rem = blockIdx.x;
+  const int nt = (NP + 1 - kn + 63) / 64;
+  while (rem >= nt - tj) { rem -= nt - tj; tj++; }
+  const int ti = tj + rem;
+  const int r0 = kn + 64 * ti, c0 = kn + 64 * tj;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < 64 * 8; t += 256) {
+    const int r = t >> 3, c = t & 7;
+    const int gi = r0 + r, gj = c0 + r;
+    Ls[r][c] = (gi <= NP) ? ((gi - k0 > c) ? Ab[(size_t)gi * ld + k0 + c] : 0.0) : 0.0;
+    Ts[r][c] = (gj < NP) ? Tb[(size_t)gj * 8 + c] : 0.0;
+  }
+  __syncthreads();
+  const int l = tid & 63, w = tid >> 6, lr = l >> 4, lc = l & 15;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int st = w * 4 + q, si = st >> 2, sj = st & 3;      // 16 sub-tiles of 16 x 16, four per wave
+    if (ti == tj && sj > si) continue;                        // strictly upper sub-tiles of a diagonal tile
+    v4f64_l acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gi = r0 + 16 * si + lr + 4 * r, gj = c0 + 16 * sj + lc;
+      acc[r] = (gi <= NP && gj < NP) ? Ab[(size_t)gi * ld + gj] : 0.0;
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * si + lc][lr], Ts[16 * sj + lc][lr], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * si + lc][4 + lr], Ts[16 * sj + lc][4 + lr], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gi = r0 + 16 * si + lr + 4 * r, gj = c0 + 16 * sj + lc;
+      if (gi <= NP && gj < NP && gj <= gi) Ab[(size_t)gi * ld + gj] = acc[r];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- host side
 struct BigStore {
   BigView b{};
@@ -329,6 +440,8 @@ struct BigStore {
   std::vector<void *> bufs;
   int *h_cnt = nullptr;
   int *d_vcnt = nullptr, *d_fill = nullptr;
+  double *d_Ab = nullptr, *d_Tb = nullptr; int *d_ord = nullptr;   // dense solver (allocated by big_build)
+  int NP = 0, ld = 0;
   void release() { for (void *p : bufs) hipFree(p); bufs.clear(); if (h_cnt) hipHostFree(h_cnt); h_cnt = nullptr; b = BigView(); g = GbaBigView(); }
 };
 
@@ -399,6 +512,8 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
   BIGCHK(al((void **)&b.poses, (size_t)W * 12 * 8));
   const size_t n6 = (size_t)6 * W;
   BIGCHK(al((void **)&b.H, n6 * n6 * 8)); BIGCHK(al((void **)&b.g, n6 * 8)); BIGCHK(al((void **)&b.r, 8));
+  s.NP = (int)((n6 + 7) / 8 * 8); s.ld = (int)((s.NP + 63) / 64 * 64);
+  BIGCHK(al((void **)&s.d_Ab, (size_t)(s.NP + 1) * s.ld * 8)); BIGCHK(al((void **)&s.d_Tb, (size_t)(s.NP + 1) * 8 * 8)); BIGCHK(al((void **)&s.d_ord, n6 * 4));
   BIGCHK(hipMemsetAsync(s.d_fill, 0, (size_t)b.capV * 4, st));
   BIGCHK(hipMemsetAsync(b.vptr, 0, (size_t)(V + 1) * 4, st));
   int E = 0;
@@ -450,6 +565,38 @@ inline int big_residual(BigStore &s, hipStream_t st, const double *poses, double
   BIGCHK(hipStreamSynchronize(st));
   BIGCHK(hipMemcpyAsync(r, b.r, 8, hipMemcpyDeviceToHost, st));
   BIGCHK(hipStreamSynchronize(st));
+  return VBA_OK;
+}
+
+// (H + u D) dxi = -g with the gauge of VM:452-455, H / g = the device buffers of the last big_hessian (before the gauge).
+// ord = Eigen's pivot order (host), hd = diag after the gauge.  The O(n^3) factorisation runs on the device, the O(n^2) back
+// substitution on the host.
+inline int big_solve(BigStore &s, hipStream_t st, const int *ord, double u, double *dxi, std::string &err) {
+  const int n = 6 * s.b.W, NP = s.NP, ld = s.ld;
+  BIGCHK(hipMemcpyAsync(s.d_ord, ord, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  const long long tot = (long long)(NP + 1) * NP;
+  hipLaunchKernelGGL(k_bigl_setup, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, s.b.H, s.b.g, s.d_ord, n, NP, ld, u, s.d_Ab);
+  for (int k0 = 0; k0 < NP; k0 += 8) {
+    hipLaunchKernelGGL(k_bigl_panel, dim3(1), dim3(256), 0, st, s.d_Ab, s.d_Tb, NP, ld, k0);
+    const int kn = k0 + 8;
+    if (kn <= NP) {
+      const int nt = (NP + 1 - kn + 63) / 64;
+      if (nt > 0) hipLaunchKernelGGL(k_bigl_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, s.d_Ab, s.d_Tb, NP, ld, k0);
+    }
+  }
+  BIGCHK(hipGetLastError());
+  std::vector<double> L((size_t)(NP + 1) * ld);
+  BIGCHK(hipStreamSynchronize(st));
+  BIGCHK(hipMemcpyAsync(L.data(), s.d_Ab, L.size() * 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipStreamSynchronize(st));
+  std::vector<double> x(n);
+  for (int j = 0; j < n; j++) x[j] = L[(size_t)NP * ld + j];                    // z = D^-1 L^-1 P (-g)
+  for (int i = n - 1; i >= 0; i--) {                                            // x = L^-T z
+    const double xi = x[i];
+    const double *row = &L[(size_t)i * ld];
+    for (int j = 0; j < i; j++) x[j] -= row[j] * xi;
+  }
+  for (int i = 0; i < n; i++) dxi[ord[i]] = x[i];
   return VBA_OK;
 }
 

@@ -1061,9 +1061,21 @@ static int big_damping_iter(vba_ctx *c, int W, double *poses, std::vector<double
     if (it == 0) resis2[0] = residual1;
     for (int r = 0; r < 6; r++) for (int k = 0; k < n; k++) { Hess[(size_t)r * n + k] = 0; Hess[(size_t)k * n + r] = 0; }
     for (int r = 0; r < 6; r++) { Hess[(size_t)r * n + r] = 1; JacT[r] = 0; }
-    A = Hess;
-    for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * Hess[(size_t)r * n + r]; rhs[r] = -JacT[r]; }
-    vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), n);     // VM:458
+    static const bool host_solve = getenv("VBA_BIG_HOST_SOLVE") != nullptr;   // diagnostic: Eigen-style LDLT on the host
+    if (host_solve) {
+      A = Hess;
+      for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * Hess[(size_t)r * n + r]; rhs[r] = -JacT[r]; }
+      vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), n);   // VM:458
+    } else {
+      // pivot order of Eigen's LDLT (largest |stored diagonal| first, first index wins ties), then the device factorisation
+      std::vector<int> ord(n);
+      for (int r = 0; r < n; r++) ord[r] = r;
+      std::vector<double> dabs(n);
+      for (int r = 0; r < n; r++) dabs[r] = std::fabs(Hess[(size_t)r * n + r] + u * Hess[(size_t)r * n + r]);
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dabs[a] > dabs[b]; });
+      int st2 = big_solve(S, c->stream, ord.data(), u, dxi.data(), c->err);
+      if (st2) return st2;
+    }
     for (int j = 0; j < W; j++) {
       double E[9];
       vbh::so3_exp(&dxi[6 * j], E);
