@@ -221,7 +221,6 @@ def hba_window(capi, torch, reps=10, cpu=True):
     res = {"workload": "10 keyframes x %d pts, GBA voxel 2 m, max_iter 1, thread_num 2" % wl.n_pts, "window_ms": 1e3 * dt, "windows_per_s": 1.0 / dt,
            "planar_voxels": ctx.size(), "edges": int(len(out["edges"])), "submap_cloud_points": int(len(out["cloud"])),
            "what": "host clouds uploaded per call; octree build, 4 LM iterations, edges, submap cloud fetched"}
-    ctx.close()
     if cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_api
@@ -230,6 +229,26 @@ def hba_window(capi, torch, reps=10, cpu=True):
         t0 = time.perf_counter()
         oracle_api.hba_add_edge(clouds, poses, cfg, 1, 2)
         res["cpu_port_window_ms"] = 1e3 * (time.perf_counter() - t0)
+    # top layer: all submaps in one window (voxelslam.cpp:3103-3113) -> the sparse any-window path with the dense LDL^T in HBM
+    Wt = 60
+    wt = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="top_w%d" % Wt, win_size=Wt, n_pts=10000)
+    st_ = synth.make_scans(wt)
+    clouds_t = [p.astype(np.float32).astype(np.float64) for p in st_["points"]]
+    poses_t = synth.poses_flat(st_["R0"], st_["p0"])
+    ctx.hba_add_edge(clouds_t, poses_t, *gba, 2, 5, want_cloud=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out_t = ctx.hba_add_edge(clouds_t, poses_t, *gba, 2, 5, want_cloud=False)
+    torch.cuda.synchronize()
+    res["top_level"] = {"workload": "%d submaps x %d pts in ONE window (360 x 360 system), 2 rounds, thread_num 5" % (Wt, wt.n_pts),
+                        "ms": 1e3 * (time.perf_counter() - t0), "edges": int(len(out_t["edges"]))}
+    if cpu:
+        o = ctx.opt
+        cfg = oracle_api.gba_cfg13(gba[0], gba[1], gba[2], o.voxel_size, o.min_eigen_value, list(o.plane_eigen_value_thre), o.max_layer)
+        t0 = time.perf_counter()
+        oracle_api.hba_add_edge(clouds_t, poses_t, cfg, 2, 5, want_cloud=False)
+        res["top_level"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
+    ctx.close()
     return res
 
 
