@@ -475,13 +475,50 @@ __device__ __forceinline__ void slot_load(const FactorView &f, int v, int fi, in
   }
 }
 
+// Device-resident LM loop, single rank: the accept / reject bookkeeping of the PREVIOUS iteration (VM:467-494) rides in the
+// prologue of the Hessian pass instead of being a kernel of its own.  Every workgroup re-derives the decision from r1 and the
+// residual pass' partials (same summation order everywhere, so the decision is bit-identical), runs only after an accepted
+// step (then on the trial poses xt, which the bookkeeping copies to x), and workgroup 0 writes the new LM state — nothing a
+// late workgroup still reads depends on what workgroup 0 changes.  (vba_kernels_lm.hpp defines the pieces.)
+struct LmDev;
+__device__ int lm_prev_stop(const LmDev *s);
+__device__ double lm_r1(const LmDev *s);
+__device__ const double *lm_xt(const LmDev *s);
+__device__ void lm_update_apply(LmDev *s, double r2, int W);
+__device__ __forceinline__ double lm_sum_partials(const double *__restrict__ r2_dev, int nb, int lane) {   // one wave; every lane gets the sum
+  double pv[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int b = lane + 64 * k; pv[k] = r2_dev[(nb > 0 && b < nb) ? b : 0]; }
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc += (lane + 64 * k < nb) ? pv[k] : 0.0;
+  for (int b = lane + 512; b < nb; b += 64) acc += r2_dev[b];
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  return acc;
+}
+
 template <int W>
 __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, const double *__restrict__ poses, int head, int end,
                                                              int ntiles, double *__restrict__ partial, const int *__restrict__ gate,
-                                                             long long *__restrict__ stamps) {
+                                                             long long *__restrict__ stamps, LmDev *lm, const double *__restrict__ k4_partial, int k4_nb) {
   using C = HessCfg2<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int gate_v = gate ? *gate : 1;        // consumed after the first tile's loads have been requested (one trip, not two)
+  __shared__ int lm_dec[2];
+  int gate_v = (gate && !lm) ? *gate : 1;     // consumed after the first tile's loads have been requested (one trip, not two)
+  double lm_r2 = 0.0;
+  if (lm) {
+    if (threadIdx.x < 64) {
+      lm_r2 = lm_sum_partials(k4_partial, k4_nb, threadIdx.x);
+      if (threadIdx.x == 0) {
+        const double r1 = lm_r1(lm);
+        const int stop = lm_prev_stop(lm);
+        const bool accept = (r1 - lm_r2) > 0, nstop = fabs((r1 - lm_r2) / r1) < 1e-6;
+        lm_dec[0] = (!stop && accept && !nstop) ? 1 : 0;
+        lm_dec[1] = stop;
+      }
+    }
+    poses = lm_xt(lm);
+  }
   // diagnostic stamps (stamps == nullptr in production): per workgroup [start, prologue, A0, B0, A1, B1, ..., reduce, end]
 #define VBA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
   VBA_STAMP(0);
@@ -509,6 +546,11 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
   asm volatile("" : "+v"(nx.n));
   if (gate_v == 0) return;                    // uniform
   __syncthreads();
+  if (lm) {
+    const int run = lm_dec[0], was_stopped = lm_dec[1];
+    if (blockIdx.x == 0 && threadIdx.x < 64 && !was_stopped) lm_update_apply(lm, lm_r2, W);
+    if (!run) return;                         // uniform: rejected step or converged -> no Hessian pass (VM:443)
+  }
   VBA_STAMP(1);
   int stamp_i = 2;
 

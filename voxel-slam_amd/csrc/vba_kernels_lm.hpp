@@ -390,31 +390,19 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
 // nb > 0: r2 is first summed here from the residual pass' nb workgroup partials (single rank: saves one launch);
 // nb == 0: r2_dev already holds the (all-reduced) scalar.  One wave; every lane takes the (uniform) decision so that the
 // pose copy x <- x_temp is a parallel copy and no dependent chain of single-lane global accesses remains.
-__global__ __launch_bounds__(64) void k_lm_update(LmDev *s, const double *__restrict__ r2_dev, int nb, int W) {
-  const int stop = s->stop, ntr = s->n_trace, mtr = s->max_trace, it = s->iter;
+__device__ int lm_prev_stop(const LmDev *s) { return s->stop; }
+__device__ double lm_r1(const LmDev *s) { return s->r1; }
+__device__ const double *lm_xt(const LmDev *s) { return s->xt; }
+
+// One wave (all 64 lanes call it with the same r2).  Reads of the state come first, in one batch.
+__device__ void lm_update_apply(LmDev *s, double r2, int W) {
+  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter;
   const double r1 = s->r1, q1 = s->q1, u0 = s->u, v0 = s->v;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   double xt0 = 0.0, xt1 = 0.0, xt2 = 0.0;                 // up to 192 pose scalars = 3 per lane
   if (lane < 12 * W) xt0 = s->xt[lane];
   if (lane + 64 < 12 * W) xt1 = s->xt[lane + 64];
   if (lane + 128 < 12 * W) xt2 = s->xt[lane + 128];
-  double pv[8];                                           // the residual pass' partials, requested with the state above
-#pragma unroll
-  for (int k = 0; k < 8; k++) { const int b = lane + 64 * k; pv[k] = r2_dev[(nb > 0 && b < nb) ? b : 0]; }
-#pragma unroll
-  for (int k = 0; k < 8; k++) asm volatile("" : "+v"(pv[k]));
-  if (stop) return;
-  double r2;
-  if (nb > 0) {
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) acc += (lane + 64 * k < nb) ? pv[k] : 0.0;
-    for (int b = lane + 512; b < nb; b += 64) acc += r2_dev[b];
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    r2 = acc;
-  } else {
-    r2 = pv[0];
-  }
   double q = r1 - r2, u = u0, v = v0;
   const bool accept = q > 0;
   if (accept) {                                             // VM:473-483
@@ -447,6 +435,14 @@ __global__ __launch_bounds__(64) void k_lm_update(LmDev *s, const double *__rest
   s->stop = nstop;
   s->run_res = nstop ? 0 : 1;
   s->run_hess = (accept && !nstop) ? 1 : 0;
+}
+
+// Stand-alone form (multi-rank flow, the last iteration of a call, callers that want the flags after every iteration).
+__global__ __launch_bounds__(64) void k_lm_update(LmDev *s, const double *__restrict__ r2_dev, int nb, int W) {
+  const int stop = s->stop;
+  const double r2 = (nb > 0) ? lm_sum_partials(r2_dev, nb, threadIdx.x) : r2_dev[0];
+  if (stop) return;
+  lm_update_apply(s, r2, W);
 }
 
 }  // namespace vba

@@ -79,7 +79,8 @@ struct vba_ctx {
   hipEvent_t lm_up_ev[kLmRing] = {nullptr};
   int lm_up_next = 0;
   double *d_raw = nullptr;        // last valid all-reduced [H|g|r] (multi-rank only; single rank reads d_out in place)
-  struct { bool active = false; int thd_num = 2; bool have_hess = false; } lm;   // have_hess: [H|g|r] of the next solve is already reduced (multi-rank)
+  struct { bool active = false; int thd_num = 2; bool have_hess = false; bool pending_update = false; int k4_nb = 0; } lm;   // pending_update: the accept/reject step of the last iteration rides in the next Hessian pass
+  double *d_k4part = nullptr;     // residual-pass partials of the LM loop (the Hessian pass reuses d_partial while they are still read)   // have_hess: [H|g|r] of the next solve is already reduced (multi-rank)
   std::vector<double> trace;
 
   // device-resident LI-BA (vba_kernels_li.hpp)
@@ -172,7 +173,7 @@ int upload_poses(vba_ctx *c, const double *poses) {
 }
 
 template <int W>
-int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out) {
+int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out, LmDev *lm, const double *k4p, int k4nb) {
   using C = HessCfg2<W>;
   const int ntiles = (end - head + C::TV - 1) / C::TV;
   int nb = ntiles < kMaxBlocksHess ? ntiles : kMaxBlocksHess;
@@ -190,7 +191,7 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
     hipMemsetAsync(d_st, 0, (size_t)kMaxBlocksHess * 16 * 8, c->stream);
     stamps = d_st;
   }
-  hipLaunchKernelGGL(k_hessian2<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate, stamps);
+  hipLaunchKernelGGL(k_hessian2<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate, stamps, lm, k4p, k4nb);
   if (want_stamps) {
     std::vector<long long> h((size_t)nb * 16);
     hipStreamSynchronize(c->stream);
@@ -210,17 +211,17 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
   return VBA_OK;
 }
 
-int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb) {
+int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0) {
   switch (c->opt.win_size) {
-    case 2: return launch_hessian2_t<2>(c, pd, gate, head, end, nb);
-    case 3: return launch_hessian2_t<3>(c, pd, gate, head, end, nb);
-    case 4: return launch_hessian2_t<4>(c, pd, gate, head, end, nb);
-    case 5: return launch_hessian2_t<5>(c, pd, gate, head, end, nb);
-    case 6: return launch_hessian2_t<6>(c, pd, gate, head, end, nb);
-    case 8: return launch_hessian2_t<8>(c, pd, gate, head, end, nb);
-    case 10: return launch_hessian2_t<10>(c, pd, gate, head, end, nb);
-    case 12: return launch_hessian2_t<12>(c, pd, gate, head, end, nb);
-    case 16: return launch_hessian2_t<16>(c, pd, gate, head, end, nb);
+    case 2: return launch_hessian2_t<2>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 3: return launch_hessian2_t<3>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 4: return launch_hessian2_t<4>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 5: return launch_hessian2_t<5>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 6: return launch_hessian2_t<6>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 8: return launch_hessian2_t<8>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 10: return launch_hessian2_t<10>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 12: return launch_hessian2_t<12>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    case 16: return launch_hessian2_t<16>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
     default: return VBA_ERR_UNSUPPORTED_WINDOW;
   }
 }
@@ -243,23 +244,24 @@ void k4_stamps_dump(vba_ctx *c, int nb, bool before) {
   fprintf(stderr, "[k4 stamps] %d waves: loads+transforms %.0f, eigen %.0f, stores+reduce %.0f cycles (mean per wave); last wave ends at %.0f cycles\n", n, a / n, e / n, w / n, last);
 }
 
-void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, int nb) {
+void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, int nb, double *dst = nullptr) {
+  double *part = dst ? dst : c->d_partial;
   static const bool want_stamps = getenv("VBA_K4_STAMPS") != nullptr;   // diagnostic switch, off in production
   if (want_stamps) k4_stamps_dump(c, nb, true);
   // below ~1 wave per SIMD the pass is latency-bound: one load batch; above it, two batches for 4-wave occupancy
   const bool big = nb > 2048;
-#define VBA_RES_CASE(WW) case WW: if (big) hipLaunchKernelGGL((k_residual_w<WW, 3>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); \
-    else hipLaunchKernelGGL((k_residual_w<WW, 1>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate); break;
+#define VBA_RES_CASE(WW) case WW: if (big) hipLaunchKernelGGL((k_residual_w<WW, 3>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate); \
+    else hipLaunchKernelGGL((k_residual_w<WW, 1>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate); break;
   switch (c->opt.win_size) {
     VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(8) VBA_RES_CASE(10) VBA_RES_CASE(12)
-    default: hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, c->d_partial, gate);
+    default: hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate);
   }
 #undef VBA_RES_CASE
   if (want_stamps) k4_stamps_dump(c, nb, false);
 }
 
 // device passes on device-resident poses (gate == nullptr: unconditional)
-int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end) {
+int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0) {
   const int W = c->opt.win_size, nout = nout_tl(W);
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)nout * sizeof(double), c->stream));
@@ -267,7 +269,7 @@ int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head,
     int nb = 0;
     TimedSpan s1{}, s2{};
     span_begin(c, "hessian", s1);
-    int st = launch_hessian(c, poses_dev, gate, head, end, &nb);
+    int st = launch_hessian(c, poses_dev, gate, head, end, &nb, lm, k4p, k4nb);
     if (st) return st;
     span_end(c, "hessian", s1);
     span_begin(c, "reduce", s2);
@@ -431,6 +433,7 @@ void vba_destroy(vba_ctx *c) {
   c->big.release();
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
+  if (c->d_k4part) hipFree(c->d_k4part);
   if (c->li_fork) hipEventDestroy(c->li_fork);
   if (c->li_join) hipEventDestroy(c->li_join);
   if (c->li_stream) hipStreamDestroy(c->li_stream);
@@ -566,7 +569,7 @@ int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   { const char *e = getenv("VBA_DEBUG_SOLVE"); h->pad = e ? atoi(e) : 0; }   // timing ablation knob (0 in production)
   HIPCHK(c, hipMemcpyAsync(c->d_lm, h, sizeof(LmDev), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->lm_up_ev[slot], c->stream));
-  c->lm.active = true; c->lm.thd_num = thd_num; c->lm.have_hess = false;
+  c->lm.active = true; c->lm.thd_num = thd_num; c->lm.have_hess = false; c->lm.pending_update = false;
   c->trace.clear();
   return VBA_OK;
 }
@@ -596,7 +599,15 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   // iteration's Hessian; on a reject the solve keeps using its saved copy (`raw`), exactly as VM:443 skips divide_thread.
   const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
   int st = VBA_OK;
-  if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);   // divide_thread  VM:445 (skipped on device after a reject)
+  static const bool no_fuse = getenv("VBA_NO_FUSED_UPDATE") != nullptr;   // diagnostic: accept/reject always as its own kernel
+  if (!(copy_raw && c->lm.have_hess)) {
+    if (c->lm.pending_update) {               // the previous iteration's accept/reject rides in this pass (runs on xt after an accepted step)
+      st = hessian_pass(c, x_dev, run_hess, 0, V, c->d_lm, c->d_k4part, c->lm.k4_nb);
+      c->lm.pending_update = false;
+    } else {
+      st = hessian_pass(c, x_dev, run_hess, 0, V);   // divide_thread  VM:445 (skipped on device after a reject)
+    }
+  }
   if (st) return st;
   TimedSpan sp{};
   span_begin(c, "solve", sp);
@@ -638,11 +649,14 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
     hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out + (nout_tl(W) - 1), 0, W);
   } else {
     const int nb = (V + 63) / 64;
+    if (!c->d_k4part) HIPCHK(c, hipMalloc((void **)&c->d_k4part, (size_t)65536 * sizeof(double)));
+    const bool fuse = !no_fuse && nb <= 65536 && !(accepted || stop);
     TimedSpan s1{};
     span_begin(c, "residual", s1);
-    launch_residual(c, xt_dev, run_res, 0, V, nb);
+    launch_residual(c, xt_dev, run_res, 0, V, nb, c->d_k4part);
     span_end(c, "residual", s1);
-    hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_partial, nb, W);   // sums the partials itself
+    if (fuse) { c->lm.pending_update = true; c->lm.k4_nb = nb; }
+    else hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_k4part, nb, W);   // sums the partials itself
   }
   HIPCHK(c, hipGetLastError());
   if (accepted || stop) {
@@ -657,6 +671,10 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
 int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (!c->lm.active) return VBA_ERR_BAD_ARG;
   const int W = c->opt.win_size, n = 6 * W;
+  if (c->lm.pending_update) {                 // the last iteration's accept/reject has no Hessian pass to ride in
+    hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_k4part, c->lm.k4_nb, W);
+    c->lm.pending_update = false;
+  }
   if (!poses && !hess && !resis2) { c->lm.active = false; return VBA_OK; }    // nothing requested: no synchronisation
   HIPCHK(c, hipStreamSynchronize(c->stream));      // drain first (D2H copies queued behind in-flight kernels complete much later, see li_ba_device)
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
