@@ -252,6 +252,35 @@ def hba_window(capi, torch, reps=10, cpu=True):
     return res
 
 
+def odometry_update(capi, torch, wl, scans, reps=10):
+    """lio_state_estimation (voxelslam.cpp:962-1098) of one 200k-point scan against the full-window map: device point loop
+    (world covariance, hash lookup + octant descent, 3-sigma gate, 34 weighted sums) x <= 4 EKF iterations, host 15x15 algebra."""
+    from voxel_slam_amd import synth
+    W = wl.win_size
+    poses = synth.poses_flat(scans["R_gt"], scans["p_gt"])
+    ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+    rng = np.random.default_rng(1)
+
+    def rand_var(n, scale):
+        A = rng.normal(0, scale, (n, 3, 3))
+        return np.ascontiguousarray((A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)).reshape(n, 9))
+    for i in range(W):
+        ctx.cut_voxel(i, scans["points"][i], poses[i], var=rand_var(len(scans["points"][i]), 0.01), multi=True)
+    ctx.recut(W, poses, multi=True)
+    ctx.margi(W, poses, jour=0.0)                  # plane_update runs inside margi
+    k = W - 1
+    state = np.zeros(25); state[1:10] = scans["R_gt"][k].ravel(); state[10:13] = scans["p_gt"][k] + 0.01; state[22:25] = [0, 0, -9.8]
+    cov = np.eye(15) * 1e-4
+    pts = scans["points"][k]; var_b = rand_var(len(pts), 0.005)
+    ctx.lio_state_estimation(pts, var_b, state, cov)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ok, st, cv = ctx.lio_state_estimation(pts, var_b, state, cov)
+    dt = (time.perf_counter() - t0) / reps
+    ctx.close()
+    return {"ms_per_scan": 1e3 * dt, "points": int(len(pts)), "converged": bool(ok), "what": "points + covariances uploaded per call"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,12 +447,13 @@ def main():
     if world == 1 and not args.no_scaled:
         scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16)
 
-    cold = lms = liv = hba = None
+    cold = lms = liv = hba = odo = None
     if world == 1 and not args.no_scaled:
         cold = cold_residual_pass(ctx, torch, poses0, V_local, occ, W)
         liv = li_variant(ctx, capi, wl, scans, poses0)
         lms = local_mapping_step(capi, torch, wl, scans, poses0)
         hba = hba_window(capi, torch, cpu=not args.no_cpu_baseline)
+        odo = odometry_update(capi, torch, wl, scans)
     roof["cold"] = cold
 
     if rank == 0:
@@ -440,6 +470,7 @@ def main():
             "local_mapping_step": lms,
             "li_ba_variant": liv,
             "hba_window": hba,
+            "odometry_update": odo,
             "full_window_rebuild": {"points": n_points, "wall_ms": 1e3 * t_rebuild, "insert_device_ms": 1e-3 * t_ins / max(n_rebuild, 1),
                                     "recut_extract_device_ms": 1e-3 * t_rec / max(n_rebuild, 1),
                                     "insert_algorithmic_GBps": n_points * 24 / (t_ins / max(n_rebuild, 1) * 1e-6) / 1e9 if t_ins > 0 else None},
