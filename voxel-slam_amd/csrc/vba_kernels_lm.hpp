@@ -302,9 +302,12 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
   if (tid < W)
 #pragma unroll
     for (int k = 0; k < 12; k++) xr[k] = s->x[12 * tid + k];
-  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter;
+  const long long t_begin = clock64();
+  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
   const double u = s->u, r_v = copy_raw ? 0.0 : red[C2::RB];
   if (stop) return;
+  long long *stamps = ((dbg & 16) && tid == 0) ? s->stamps : nullptr;
+  if (stamps) stamps[0] = t_begin;
   const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
   if (copy_raw) {
     if (calc)
@@ -361,10 +364,13 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
     a = (i > n || i < j) ? 0.0 : a;
     return (j >= n) ? ((i == j) ? 1.0 : 0.0) : a;
   };
-  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem);
+  if (stamps) stamps[1] = clock64();
+  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem, (dbg & 16) ? s->stamps : nullptr);
+  if (stamps) stamps[3] = clock64();
   if (tid < n) xs[tid] = Lst[LC::lat(n, tid)];
   __syncthreads();
   const double x = ldlt_backsub<NP>(Lst, xs, n);
+  if (stamps) stamps[4] = clock64();
   if (tid < n) dxs[ord[tid]] = x;
   __syncthreads();
   if (tid < W) {                                                                                        // VM:460-464
@@ -384,6 +390,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
   if ((tid & 63) == 0) red8[tid >> 6] = q;
   __syncthreads();
   if (tid == 0) s->q1 = 0.5 * (red8[0] + red8[1] + red8[2] + red8[3]);
+  if (stamps) stamps[5] = clock64();
 }
 
 // Accept / reject bookkeeping of VM:467-494 (one thread).  r2_dev = the reduced residual of the trial poses.

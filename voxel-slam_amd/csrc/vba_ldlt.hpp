@@ -96,12 +96,17 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
         const double tmc = (ok && ib > c) ? x[c] : 0.0;   // T = L d = the unscaled value (0 for a zero pivot)
         Lk[ib * LS + c] = lv;
         Tp[i * LS + c] = -tmc;
+        // the panel step is issue-bound (one wave per SIMD, ~4 cycles per f64 instruction): scale the column once
+        // (7 - c multiplications) so that every update is a single FMA
+        double Lc[8];
 #pragma unroll
-        for (int c2 = c + 1; c2 < 8; c2++) x[c2] = fma(-(tmc * D[c2][c]), dinv, x[c2]);
+        for (int r = c + 1; r < 8; r++) Lc[r] = D[r][c] * dinv;                          // L[r][c] of the block (0 for a zero pivot: no update)
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; c2++) x[c2] = fma(-tmc, Lc[c2], x[c2]);
 #pragma unroll
         for (int r = c + 1; r < 8; r++)
 #pragma unroll
-          for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] = fma(-(D[r][c] * D[c2][c]), dinv, D[r][c2]);
+          for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] = fma(-D[r][c], Lc[c2], D[r][c2]);
       }
     }
     __syncthreads();

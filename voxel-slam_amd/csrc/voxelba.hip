@@ -692,7 +692,12 @@ int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (hess) std::memcpy(hess, c->h_pin + 32768, (size_t)n * n * sizeof(double));
   if (resis2) { resis2[0] = h->resis_first; resis2[1] = h->r2; }
   c->trace.assign(h->trace, h->trace + 5 * h->n_trace);
-  if (h->pad & 16) {
+  if ((h->pad & 16) && !getenv("VBA_SOLVE_OLD")) {
+    fprintf(stderr, "[k_lm_solve_m cycles] prologue %lld | tile load %lld | factorisation %lld | backsub %lld | epilogue %lld | panels:", h->stamps[1] - h->stamps[0],
+            h->stamps[2] - h->stamps[1], h->stamps[3] - h->stamps[2], h->stamps[4] - h->stamps[3], h->stamps[5] - h->stamps[4]);
+    for (int kb = 0; kb < 8; kb++) fprintf(stderr, " %lld+%lld", h->stamps[9 + 2 * kb] - h->stamps[8 + 2 * kb], kb < 7 ? h->stamps[10 + 2 * kb] - h->stamps[9 + 2 * kb] : 0LL);
+    fprintf(stderr, "\n");
+  } else if (h->pad & 16) {
     fprintf(stderr, "[solve stamps, shader cycles rel. to factorisation start]");
     for (int i = 1; i <= 30; i++) fprintf(stderr, " %lld", h->stamps[i] - h->stamps[50]);
     fprintf(stderr, " | subst end %lld | shader clock %.0f MHz\n", h->stamps[40] - h->stamps[0],
