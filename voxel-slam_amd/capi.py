@@ -387,6 +387,7 @@ class Context:
         that stream current.  (Issuing it on torch's default stream instead leaves it unordered against the context's own
         non-blocking stream: the sum then races with k_reduce_partials.)"""
         cache = {}
+        streams = {}
 
         def hook(ptr, n, stream):
             key = (ptr, n)
@@ -394,9 +395,15 @@ class Context:
                 class _Ext:
                     __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
                 cache[key] = torch.as_tensor(_Ext(), device="cuda")
-            ext = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.default_stream()
-            with torch.cuda.stream(ext):
+            skey = int(stream) if stream else 0
+            if skey not in streams:                         # (the hook runs once per LM iteration: keep its host cost down)
+                streams[skey] = torch.cuda.ExternalStream(skey) if skey else torch.cuda.default_stream()
+            ext = streams[skey]
+            if torch.cuda.current_stream() == ext:
                 dist.all_reduce(cache[key], op=dist.ReduceOp.SUM)
+            else:
+                with torch.cuda.stream(ext):
+                    dist.all_reduce(cache[key], op=dist.ReduceOp.SUM)
             return 0
         self.set_allreduce(hook)
 
