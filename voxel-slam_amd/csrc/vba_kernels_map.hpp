@@ -1220,8 +1220,8 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   const int W = s.opt.win_size;
   if (win_count < 1 || win_count > W || !poses) return VBA_ERR_BAD_ARG;
   if (!s.allocated) return VBA_OK;
-  int r = map_read_counters(s, st, err);
-  if (r) return r;
+  int r = VBA_OK;
+  if (s.cnt_stale) { r = map_read_counters(s, st, err); if (r) return r; }    // (the recut before the optimisation left them current)
   const int slot0 = s.mp[0];
   r = map_ensure(s, st, 0, 0, (size_t)s.h_cnt[CNT_FIX] + (size_t)s.npts[slot0] + 1, err);
   if (r) return r;
