@@ -248,6 +248,27 @@ def hba_window(capi, torch, reps=10, cpu=True):
         t0 = time.perf_counter()
         oracle_api.hba_add_edge(clouds_t, poses_t, cfg, 2, 5, want_cloud=False)
         res["top_level"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
+    # the whole hierarchy on one map (BASELINE configs[4] shape, reduced): 60 keyframes -> 11 windows of 10 -> 11 submaps -> top BA
+    nk = 60
+    wk = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="hba_kf%d" % nk, win_size=nk, n_pts=20000)
+    sk = synth.make_scans(wk)
+    clouds_k = [p.astype(np.float32).astype(np.float64) for p in sk["points"]]
+    x0k = synth.poses_flat(sk["R0"], sk["p0"])
+    ctx.hba_global(clouds_k, x0k, x0k, *gba, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e1, e2 = ctx.hba_global(clouds_k, x0k, x0k, *gba, 2)
+    torch.cuda.synchronize()
+    res["hierarchy"] = {"workload": "%d keyframes x %d pts: windows of 10 every 5, then the top-level BA over the submaps" % (nk, wk.n_pts),
+                        "ms": 1e3 * (time.perf_counter() - t0), "edges_bottom": int(len(e1)), "edges_top": int(len(e2))}
+    if cpu:
+        t0 = time.perf_counter()
+        subs, firsts = [], []
+        for start in range(0, nk - 10 + 1, 5):
+            r = oracle_api.hba_add_edge(clouds_k[start:start + 10], x0k[start:start + 10], cfg, 1, 2)
+            subs.append(r["cloud"]); firsts.append(start)
+        oracle_api.hba_add_edge(subs, x0k[firsts], cfg, 2, 5, want_cloud=False)
+        res["hierarchy"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
     ctx.close()
     return res
 

@@ -240,6 +240,17 @@ int vba_hba_add_edge(vba_ctx *ctx, int wdsize, const int *offsets, const double 
                      int thread_num, double *edges_out, int *n_edges, double *cloud_out, int *cloud_count, int *n_cloud,
                      double *resis_log, int *n_log);
 
+/* The optimisation work of thd_globalmapping (VS:3018-3141) over one map: bottom-layer windows of wdsize keyframes every
+ * mgsize keyframes (10 / 5 in the reference, VS:3033-3034) on the poses x0, each yielding edges (edges1, the reference's
+ * gba_edges1) and one submap (first keyframe's x0, the window's down-sampled cloud in that frame, VS:3084-3089); then the
+ * top-level HBA_add_edge over all submaps with the keyframes' CURRENT poses poses_now (VS:3096-3110) -> edges2.  Rows as in
+ * vba_hba_add_edge with global keyframe indices; cap1 / cap2 = row capacities of the outputs.  Queues, map switching and
+ * the GTSAM graph stay with the caller. */
+int vba_hba_global(vba_ctx *ctx, int n_kf, const int *offsets, const double *pnt_local, const double *poses_x0,
+                   const double *poses_now, double gba_voxel_size, double gba_min_eigen_value,
+                   const double *gba_eigen_value_array, int total_max_iter, int wdsize, int mgsize, double *edges1_out, int cap1,
+                   int *n_edges1, double *edges2_out, int cap2, int *n_edges2);
+
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU: voxels are sharded by root-voxel hash bucket; each rank evaluates its
  * shard and the packed [H | g | r] buffer is summed across ranks (the thread-sum of VM:571-581).

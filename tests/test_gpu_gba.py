@@ -116,3 +116,44 @@ def test_hba_add_edge_parity(oracle, name, max_iter, thread_num):
     assert same.mean() > 0.9
     np.testing.assert_allclose(got["cloud"][:k][same], want["cloud"][:k][same], rtol=0, atol=1e-4)
     ctx.close()
+
+
+def test_hba_global_hierarchy_parity(oracle):
+    """thd_globalmapping's optimisation work (VS:3018-3141) on 25 keyframes: four bottom-layer windows of 10 (stride 5) on the
+    templated kernels, their submap clouds, then the top-level window over the four submaps on the sparse path — against the
+    same orchestration of the oracle's HBA_add_edge."""
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    nkf, wd, mg = 25, 10, 5
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="room_kf", win_size=nkf, n_pts=6000)
+    s = synth.make_scans(wl)
+    clouds = [p.astype(np.float32).astype(np.float64) for p in s["points"]]
+    x0 = synth.poses_flat(s["R0"], s["p0"])
+    ctx = capi.Context(capi.options_from_workload(dataclasses.replace(wl, win_size=wd)))
+    o = ctx.opt
+    cfg = oracle.gba_cfg13(GBA["gba_voxel_size"], GBA["gba_min_eigen_value"], GBA["gba_eig"], o.voxel_size, o.min_eigen_value,
+                           list(o.plane_eigen_value_thre), o.max_layer)
+    e1, e2 = ctx.hba_global(clouds, x0, x0, GBA["gba_voxel_size"], GBA["gba_min_eigen_value"], GBA["gba_eig"], 2, wd, mg)
+    # the same hierarchy with the oracle
+    o1, subs, firsts = [], [], []
+    for start in range(0, nkf - wd + 1, mg):
+        r = oracle.hba_add_edge(clouds[start:start + wd], x0[start:start + wd], cfg, 1, 2)
+        assert r["status"] == 0
+        ee = r["edges"].copy(); ee[:, :2] += start
+        o1.append(ee); subs.append(r["cloud"]); firsts.append(start)
+    o1 = np.concatenate(o1)
+    r2 = oracle.hba_add_edge(subs, x0[firsts], cfg, 2, 5, want_cloud=False)
+    assert r2["status"] == 0
+    o2 = r2["edges"].copy()
+    o2[:, 0] = np.array(firsts)[o2[:, 0].astype(int)]; o2[:, 1] = np.array(firsts)[o2[:, 1].astype(int)]
+    assert len(e1) == len(o1) == 4 * 45
+    np.testing.assert_array_equal(e1[:, :2], o1[:, :2])
+    np.testing.assert_allclose(e1[:, 2:14], o1[:, 2:14], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(e1[:, 14:], o1[:, 14:], rtol=1e-5)
+    # top layer: the submap clouds of the two sides differ by float rounding of a few boundary points (see the window test),
+    # so its Hessian-diagonal weights agree to ~1e-3 and the relative poses to ~1e-5
+    assert len(e2) == len(o2) == 6
+    np.testing.assert_array_equal(e2[:, :2], o2[:, :2])
+    np.testing.assert_allclose(e2[:, 2:14], o2[:, 2:14], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(e2[:, 14:], o2[:, 14:], rtol=2e-2)
+    ctx.close()

@@ -26,7 +26,7 @@ EXPORTS = [
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
-    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_gba_build", "vba_hba_add_edge", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
+    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_gba_build", "vba_hba_add_edge", "vba_hba_global", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
@@ -365,6 +365,17 @@ class Context:
                                             ccnt.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nc), _p(rl), C.byref(nl)))
         return dict(poses=poses, edges=edges[:ne.value].copy(), cloud=cloud[:nc.value].copy(), cloud_count=ccnt[:nc.value].copy(),
                     resis=rl[:nl.value].copy())
+
+    def hba_global(self, clouds, poses_x0, poses_now, gba_voxel_size, gba_min_eigen_value, gba_eig, total_max_iter, wdsize=10, mgsize=5):
+        n = len(clouds)
+        off, pnt = self._ragged(clouds)
+        nwin = max(0, (n - wdsize) // mgsize + 1) if n >= wdsize else 0
+        cap1 = nwin * (wdsize * (wdsize - 1) // 2) + 1; cap2 = nwin * (nwin - 1) // 2 + 1
+        e1 = np.zeros((cap1, 20)); e2 = np.zeros((cap2, 20)); n1 = C.c_int(0); n2 = C.c_int(0)
+        self._chk(self.lib.vba_hba_global(self.h, C.c_int(n), off.ctypes.data_as(C.POINTER(C.c_int)), _p(pnt), _p(_c(poses_x0)), _p(_c(poses_now)),
+                                          C.c_double(gba_voxel_size), C.c_double(gba_min_eigen_value), _p(_c(gba_eig)), C.c_int(total_max_iter),
+                                          C.c_int(wdsize), C.c_int(mgsize), _p(e1), C.c_int(cap1), C.byref(n1), _p(e2), C.c_int(cap2), C.byref(n2)))
+        return e1[:n1.value].copy(), e2[:n2.value].copy()
 
     def set_shard(self, rank, n_ranks):
         self._chk(self.lib.vba_set_shard(self.h, C.c_int(rank), C.c_int(n_ranks)))

@@ -1228,6 +1228,67 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
   return VBA_OK;
 }
 
+// thd_globalmapping (VS:3018-3141), the optimisation work of the hierarchical global BA over one map:
+//   bottom layer  windows of `wdsize` keyframes, stride `mgsize` (VS:3033-3034, 3064-3066, 3136-3137): HBA_add_edge(xs = x0 of the
+//                 window, max_iter 1, thread_num 2) -> edges1 + one submap (pose x0 of the window's first keyframe, cloud
+//                 = the window's down-sampled points in that frame, VS:3084-3089);
+//   top layer     HBA_add_edge over all submaps with their CURRENT poses (VS:3096-3110): edges2.
+// Edge rows carry GLOBAL keyframe indices.  (Queue handling, map switching and the GTSAM pose graph stay with the caller.)
+int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_local, const double *poses_x0, const double *poses_now,
+                   double gba_voxel_size, double gba_min_eigen_value, const double *gba_eigen_value_array, int total_max_iter, int wdsize, int mgsize,
+                   double *edges1_out, int cap1, int *n_edges1, double *edges2_out, int cap2, int *n_edges2) {
+  if (n_kf < 0 || wdsize < 2 || mgsize < 1 || !offsets || !poses_x0 || !poses_now || !gba_eigen_value_array || !n_edges1 || !n_edges2 ||
+      (offsets[n_kf] > 0 && !pnt_local))
+    return VBA_ERR_BAD_ARG;
+  *n_edges1 = 0; *n_edges2 = 0;
+  std::vector<int> sub_first;                       // global id of every submap's first keyframe
+  std::vector<std::vector<double>> sub_cloud;
+  std::vector<double> edges((size_t)(wdsize * (wdsize - 1) / 2 + 1) * 20);
+  for (int start = 0; start + wdsize <= n_kf; start += mgsize) {
+    std::vector<int> off(wdsize + 1);
+    for (int i = 0; i <= wdsize; i++) off[i] = offsets[start + i] - offsets[start];
+    std::vector<double> xs(poses_x0 + (size_t)start * 12, poses_x0 + (size_t)(start + wdsize) * 12);
+    std::vector<double> cloud((size_t)(off[wdsize] > 0 ? off[wdsize] : 1) * 3);
+    std::vector<int> ccnt(off[wdsize] > 0 ? off[wdsize] : 1);
+    int ne = 0, nc = 0;
+    int st = vba_hba_add_edge(c, wdsize, off.data(), pnt_local + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
+                              gba_eigen_value_array, 1, 2, edges.data(), &ne, cloud.data(), ccnt.data(), &nc, nullptr, nullptr);
+    if (st) return st;
+    for (int e = 0; e < ne; e++) {
+      if (*n_edges1 >= cap1) return VBA_ERR_CAPACITY;
+      double *o = edges1_out + (size_t)(*n_edges1) * 20;
+      std::memcpy(o, &edges[(size_t)e * 20], 20 * sizeof(double));
+      o[0] += start; o[1] += start;
+      (*n_edges1)++;
+    }
+    cloud.resize((size_t)nc * 3);
+    sub_first.push_back(start);
+    sub_cloud.push_back(std::move(cloud));
+  }
+  const int ns = (int)sub_first.size();
+  if (ns >= 2) {
+    std::vector<int> off(ns + 1, 0);
+    for (int i = 0; i < ns; i++) off[i + 1] = off[i] + (int)(sub_cloud[i].size() / 3);
+    std::vector<double> pts((size_t)(off[ns] > 0 ? off[ns] : 1) * 3), xs((size_t)ns * 12), e2((size_t)(ns * (ns - 1) / 2 + 1) * 20);
+    for (int i = 0; i < ns; i++) {
+      std::memcpy(&pts[(size_t)off[i] * 3], sub_cloud[i].data(), sub_cloud[i].size() * sizeof(double));
+      std::memcpy(&xs[(size_t)i * 12], poses_now + (size_t)sub_first[i] * 12, 12 * sizeof(double));
+    }
+    int ne = 0;
+    int st = vba_hba_add_edge(c, ns, off.data(), pts.data(), xs.data(), gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array, total_max_iter, 5,
+                              e2.data(), &ne, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (st) return st;
+    for (int e = 0; e < ne; e++) {
+      if (*n_edges2 >= cap2) return VBA_ERR_CAPACITY;
+      double *o = edges2_out + (size_t)(*n_edges2) * 20;
+      std::memcpy(o, &e2[(size_t)e * 20], 20 * sizeof(double));
+      o[0] = sub_first[(int)e2[(size_t)e * 20]]; o[1] = sub_first[(int)e2[(size_t)e * 20 + 1]];
+      (*n_edges2)++;
+    }
+  }
+  return VBA_OK;
+}
+
 // ---------------------------------------------------------------- IMU factor (host)
 int vba_imu_preintegrate(int n, const double *t, const double *gyr, const double *acc, const double *bg, const double *ba,
                          const double *nm6, const double *nw6, double scale_gravity, double *out) {
