@@ -1244,6 +1244,15 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   std::vector<int> sub_first;                       // global id of every submap's first keyframe
   std::vector<std::vector<double>> sub_cloud;
   std::vector<double> edges((size_t)(wdsize * (wdsize - 1) / 2 + 1) * 20);
+  // the keyframe clouds go to HBM once (the stride-5 windows overlap: every keyframe is used twice)
+  double *d_all = nullptr;
+  const size_t n_all = (size_t)offsets[n_kf];
+  if (n_all > 0) {
+    HIPCHK(c, hipMalloc((void **)&d_all, n_all * 3 * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream);
+    if (e != hipSuccess) { hipFree(d_all); c->set_error(hipGetErrorString(e)); return VBA_ERR_HIP; }
+  }
+  struct Free { double *p; ~Free() { if (p) hipFree(p); } } free_all{d_all};
   for (int start = 0; start + wdsize <= n_kf; start += mgsize) {
     std::vector<int> off(wdsize + 1);
     for (int i = 0; i <= wdsize; i++) off[i] = offsets[start + i] - offsets[start];
@@ -1251,7 +1260,7 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     std::vector<double> cloud((size_t)(off[wdsize] > 0 ? off[wdsize] : 1) * 3);
     std::vector<int> ccnt(off[wdsize] > 0 ? off[wdsize] : 1);
     int ne = 0, nc = 0;
-    int st = vba_hba_add_edge(c, wdsize, off.data(), pnt_local + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
+    int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
                               gba_eigen_value_array, 1, 2, edges.data(), &ne, cloud.data(), ccnt.data(), &nc, nullptr, nullptr);
     if (st) return st;
     for (int e = 0; e < ne; e++) {
