@@ -212,6 +212,16 @@ int vba_map_dump_leaves(vba_ctx *ctx, double *out, int max_leaves);
 int vba_odom_lio_state_estimation(vba_ctx *ctx, int n, const double *pnt_body, const double *var_body, double *state,
                                   double *cov, int *ok);
 
+/* void VOXEL_SLAM::lio_state_estimation_kdtree(PVecPtr pptr) (VS:1102-1252), the odometry used while the system initialises:
+ * scan points against a point-cloud map (pl_tree, kept by the context) through an exact 5-nearest-neighbour plane fit.
+ * While the map holds fewer than 100 points the scan only seeds it (VS:1105-1118, *iterations = 0); otherwise state / cov
+ * are updated in place, the scan is appended in the refined pose and the map re-sampled on a 0.5 m grid (VS:1238-1250). */
+int vba_odom_lio_state_estimation_kdtree(vba_ctx *ctx, int n, const double *pnt_body, double *state, double *cov,
+                                         int *iterations);
+int vba_odom_kdtree_reset(vba_ctx *ctx);   /* pl_tree->clear() */
+int vba_odom_kdtree_size(vba_ctx *ctx);    /* pl_tree->size() */
+int vba_odom_kdtree_points(vba_ctx *ctx, double *xyz_out /* [size][3] */);
+
 /* ------------------------------------------------------------------------------------------------
  * Hierarchical global BA ("next #3"), one keyframe window per call.  vba_hba_add_edge accepts any
  * wdsize >= 2: a window of the context's win_size (the bottom layers use 10, VS:3033) runs on the templated device

@@ -11,6 +11,7 @@
 #include "map_oracle.hpp"
 #include "scan_oracle.hpp"
 #include "gba_oracle.hpp"
+#include "kd_oracle.hpp"
 #include <chrono>
 
 using namespace vso;
@@ -383,6 +384,22 @@ int vso_hba_add_edge(int wdsize, const int *offsets, const double *pnt, double *
   }
   if (resis_log) { for (size_t i = 0; i < rl.size(); i++) resis_log[i] = rl[i]; *n_log = (int)rl.size(); }
   return 0;
+}
+
+// ---- kd-tree odometry of the initialisation phase (kd_oracle.hpp)
+void *vso_kd_create() { return new KdOdomOracle(); }
+void vso_kd_destroy(void *h) { delete (KdOdomOracle *)h; }
+int vso_kd_tree_size(void *h) { return (int)(((KdOdomOracle *)h)->tree.size() / 3); }
+void vso_kd_tree_points(void *h, double *out) { auto &t = ((KdOdomOracle *)h)->tree; for (size_t i = 0; i < t.size(); i++) out[i] = t[i]; }
+int vso_kd_lio_state_estimation(void *h, int n, const double *pnt_body, double *state, double *cov) {
+  std::vector<V3> p(n);
+  for (int i = 0; i < n; i++) p[i] = v3_from(pnt_body + 3 * i);
+  IMUST x = state_from(state);
+  for (int i = 0; i < 225; i++) x.cov[i] = cov[i];
+  const int it = ((KdOdomOracle *)h)->lio_state_estimation_kdtree(p, x);
+  state_to(x, state);
+  for (int i = 0; i < 225; i++) cov[i] = x.cov[i];
+  return it;
 }
 
 double vso_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

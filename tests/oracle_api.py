@@ -255,6 +255,33 @@ def hba_add_edge(clouds, poses, cfg13, max_iter, thread_num, want_cloud=True):
                 resis=rl[:nl.value].reshape(-1, 2).copy())
 
 
+class KdOdom:
+    """Oracle of lio_state_estimation_kdtree (voxelslam.cpp:1102-1252)."""
+
+    def __init__(self):
+        lib().vso_kd_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().vso_kd_create())
+
+    def __del__(self):
+        try:
+            lib().vso_kd_destroy(self.h)
+        except Exception:
+            pass
+
+    def tree(self):
+        n = lib().vso_kd_tree_size(self.h)
+        out = np.zeros((max(n, 1), 3))
+        if n:
+            lib().vso_kd_tree_points(self.h, _p(out))
+        return out[:n]
+
+    def lio_state_estimation(self, pnt_body, state25, cov225):
+        pnt = _c(pnt_body); st = _c(state25).copy(); cov = _c(cov225).copy()
+        lib().vso_kd_lio_state_estimation.restype = C.c_int
+        it = lib().vso_kd_lio_state_estimation(self.h, C.c_int(len(pnt)), _p(pnt), _p(st), _p(cov))
+        return it, st, cov
+
+
 def map_key(voxel_size, pw):
     pw = _c(pw); k = (C.c_longlong * 3)()
     lib().vso_map_key(C.c_double(voxel_size), _p(pw), k)

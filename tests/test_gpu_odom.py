@@ -61,3 +61,43 @@ def test_lio_state_estimation_parity(oracle):
     assert np.abs(cov_g - cov_o).max() < 1e-9 * np.abs(cov_o).max()
     # the update pulled the prediction towards the ground truth
     assert np.abs(st_g[10:13] - s["p_gt"][k]).max() < np.abs(state[10:13] - s["p_gt"][k]).max()
+
+
+def test_lio_state_estimation_kdtree_parity(oracle):
+    """Initialisation odometry (voxelslam.cpp:1102-1252): exact 5-NN plane fit against the point-cloud map + iterated EKF, then
+    the map update (append + 0.5 m re-sampling), over a short sequence: the first scan only seeds the map."""
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], win_size=5)
+    s = synth.make_scans(wl)
+    ctx = capi.Context(capi.options_from_workload(wl))
+    ko = oracle.KdOdom()
+    rng = np.random.default_rng(17)
+    cov_g = np.eye(15) * 1e-4
+    cov_g[9:, 9:] = np.eye(6) * 1e-5
+    cov_o = cov_g.copy()
+    for k in range(wl.win_size):
+        pts = s["points"][k].astype(np.float32).astype(np.float64)          # PCL scan points are float
+        state = np.zeros(25)
+        dR = np.eye(3) if k == 0 else synth.so3_exp(rng.normal(0, np.radians(0.3), 3))
+        state[1:10] = (s["R_gt"][k] @ dR).ravel()
+        state[10:13] = s["p_gt"][k] + (0 if k == 0 else rng.normal(0, 0.03, 3))
+        state[13:16] = [0.3, 0.1, 0.0]; state[22:25] = [0, 0, -9.8]
+        it_g, st_g, cov_g2 = ctx.lio_state_estimation_kdtree(pts, state, cov_g)
+        it_o, st_o, cov_o2 = ko.lio_state_estimation(pts, state, cov_o)
+        assert it_g == it_o, (k, it_g, it_o)
+        if k == 0:
+            assert it_g == 0 and ctx.kdtree_size() == len(pts) == len(ko.tree())
+            np.testing.assert_array_equal(st_g, state)
+            continue
+        # the map points differ in the last float digit (the reference's running mean is evaluated in float, the device rounds
+        # the f64 centroid once), which moves the fitted planes by ~1e-7
+        assert np.abs(st_g - st_o).max() < 1e-5, (k, np.abs(st_g - st_o).max())
+        assert np.abs(cov_g2 - cov_o2).max() < 1e-4 * np.abs(cov_o2).max()
+        assert np.linalg.norm(st_g[10:13] - s["p_gt"][k]) < np.linalg.norm(state[10:13] - s["p_gt"][k])
+        tg, to = ctx.kdtree_points(), ko.tree()
+        assert abs(len(tg) - len(to)) <= max(2, len(to) // 500), (len(tg), len(to))   # a point within 1e-5 of a 0.5 m face may change cell
+        if len(tg) == len(to):
+            assert np.abs(tg - to).max() < 1e-4
+        cov_g, cov_o = cov_g2, cov_o2
+    ctx.close()

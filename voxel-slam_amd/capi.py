@@ -26,7 +26,7 @@ EXPORTS = [
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
-    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_gba_build", "vba_hba_add_edge", "vba_hba_global", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
+    "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_odom_lio_state_estimation_kdtree", "vba_odom_kdtree_reset", "vba_odom_kdtree_size", "vba_odom_kdtree_points", "vba_gba_build", "vba_hba_add_edge", "vba_hba_global", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
@@ -339,6 +339,20 @@ class Context:
         return bool(ok.value), state, cov
 
     # ---- multi-GPU / timing
+    def lio_state_estimation_kdtree(self, pnt_body, state25, cov225):
+        pnt = _c(pnt_body); st = _c(state25).copy(); cov = _c(cov225).copy(); it = C.c_int(0)
+        self._chk(self.lib.vba_odom_lio_state_estimation_kdtree(self.h, C.c_int(len(pnt)), _p(pnt), _p(st), _p(cov), C.byref(it)))
+        return it.value, st, cov
+
+    def kdtree_size(self):
+        return self.lib.vba_odom_kdtree_size(self.h)
+
+    def kdtree_points(self):
+        n = self.kdtree_size(); out = np.zeros((max(n, 1), 3))
+        if n:
+            self._chk(self.lib.vba_odom_kdtree_points(self.h, _p(out)))
+        return out[:n]
+
     # ---- hierarchical global BA
     @staticmethod
     def _ragged(clouds):

@@ -11,6 +11,7 @@
 #include "vba_kernels_scan.hpp"
 #include "vba_kernels_gba.hpp"
 #include "vba_kernels_big.hpp"
+#include "vba_kernels_kd.hpp"
 #include <cstddef>
 #include "vba_hostmath.hpp"
 
@@ -92,6 +93,8 @@ struct vba_ctx {
   MapStore map;
   GbaStore gba;
   BigStore big;                   // arbitrary-window path (top-level global BA)
+  double *d_kdtree[2] = {nullptr, nullptr};   // pl_tree of the initialisation odometry (float-valued xyz), ping-pong for the re-sampling
+  size_t kd_cap = 0; int kd_n = 0, kd_cur = 0;
   double *d_refpts = nullptr;     // submap cloud staging (HBA_add_edge)
   size_t refpts_doubles = 0;
 
@@ -431,6 +434,7 @@ void vba_destroy(vba_ctx *c) {
   map_free(c->map);
   c->gba.free_all();
   c->big.release();
+  for (int i = 0; i < 2; i++) if (c->d_kdtree[i]) hipFree(c->d_kdtree[i]);
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
   if (c->d_k4part) hipFree(c->d_k4part);
@@ -1022,6 +1026,132 @@ int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity
   std::memcpy(states, x.data(), (size_t)W * 25 * sizeof(double));
   if (hess) std::memcpy(hess, saved.data(), saved.size() * sizeof(double));
   if (gravity && resis2) { resis2[0] = resis_first; resis2[1] = residual2; }
+  return VBA_OK;
+}
+
+// ---------------------------------------------------------------- initialisation odometry on a point-cloud map (vba_kernels_kd.hpp)
+static int kd_reserve(vba_ctx *c, size_t pts) {
+  if (pts <= c->kd_cap) return VBA_OK;
+  size_t cap = c->kd_cap ? c->kd_cap : 65536;
+  while (cap < pts) cap *= 2;
+  for (int i = 0; i < 2; i++) {
+    double *nw = nullptr;
+    HIPCHK(c, hipMalloc((void **)&nw, cap * 3 * sizeof(double)));
+    if (c->d_kdtree[i]) {
+      if (i == c->kd_cur && c->kd_n > 0) HIPCHK(c, hipMemcpyAsync(nw, c->d_kdtree[i], (size_t)c->kd_n * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      hipFree(c->d_kdtree[i]);
+    }
+    c->d_kdtree[i] = nw;
+  }
+  c->kd_cap = cap;
+  return VBA_OK;
+}
+int vba_odom_kdtree_reset(vba_ctx *c) { c->kd_n = 0; return VBA_OK; }
+int vba_odom_kdtree_size(vba_ctx *c) { return c->kd_n; }
+int vba_odom_kdtree_points(vba_ctx *c, double *out) {
+  if (!out && c->kd_n > 0) return VBA_ERR_BAD_ARG;
+  if (c->kd_n == 0) return VBA_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(out, c->d_kdtree[c->kd_cur], (size_t)c->kd_n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VBA_OK;
+}
+
+int vba_odom_lio_state_estimation_kdtree(vba_ctx *c, int n, const double *pnt_body, double *state, double *cov, int *iterations) {
+  if (n < 0 || (n > 0 && !pnt_body) || !state || !cov) return VBA_ERR_BAD_ARG;
+  if (iterations) *iterations = 0;
+  const int DIM = VBA_DIM, nb = (n + 255) / 256;
+  int st = ensure_stage(c, ((size_t)n * 7 + (size_t)nb * 28 + 64) * sizeof(double));
+  if (st) return st;
+  double *d_pts = (double *)c->d_stage, *d_pl = d_pts + (size_t)n * 3, *d_part = d_pl + (size_t)n * 4;
+  if (n > 0) HIPCHK(c, hipMemcpyAsync(d_pts, pnt_body, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  vbh::State x_curr, x_prop;
+  std::memcpy(&x_curr, state, sizeof(x_curr));
+  auto pose_of = [](const vbh::State &x) { KdPose X; std::memcpy(X.R, x.R, sizeof(X.R)); std::memcpy(X.t, x.p, sizeof(X.t)); return X; };
+  st = kd_reserve(c, (size_t)c->kd_n + (size_t)n + 16);
+  if (st) return st;
+  if (c->kd_n < 100) {                                                       // VS:1105-1118: the map is only seeded
+    if (n > 0) hipLaunchKernelGGL(k_kd_append, dim3(nb), dim3(256), 0, c->stream, n, d_pts, pose_of(x_curr), c->d_kdtree[c->kd_cur] + (size_t)c->kd_n * 3);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->kd_n += n;
+    return VBA_OK;
+  }
+  x_prop = x_curr;
+  std::vector<double> P(cov, cov + 225), cov_inv(225), part((size_t)nb * 28);
+  vbh::inverse_pplu(P.data(), cov_inv.data(), DIM);                          // VS:1134
+  const int num_max_iter = 4;
+  int rematch_num = 0, iters = 0;
+  bool refind = true, converged_once = false;
+  double G[225];
+  std::memset(G, 0, sizeof(G));
+  for (int iter = 0; iter < num_max_iter; iter++) {
+    iters++;
+    const KdPose X = pose_of(x_curr);
+    double s28[28];
+    std::memset(s28, 0, sizeof(s28));
+    if (n > 0) {
+      if (refind) hipLaunchKernelGGL(k_kd_match, dim3(nb), dim3(256), 0, c->stream, n, d_pts, X, c->kd_n, c->d_kdtree[c->kd_cur], d_pl);
+      hipLaunchKernelGGL(k_kd_accum, dim3(nb), dim3(256), 0, c->stream, n, d_pts, X, d_pl, d_part);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (int b = 0; b < nb; b++) for (int k = 0; k < 28; k++) s28[k] += part[(size_t)b * 28 + k];
+    }
+    double HTH[36], HTz[6];
+    { int idx = 0; for (int r = 0; r < 6; r++) for (int k = r; k < 6; k++) { HTH[r * 6 + k] = s28[idx]; HTH[k * 6 + r] = s28[idx]; idx++; } }
+    for (int r = 0; r < 6; r++) HTz[r] = s28[21 + r];
+    // K_1 = (H_T_H + cov_inv / 1000)^-1 ; G(:,0:6) = K_1(:,0:6) HTH ; solution = K_1(:,0:6) HTz + vec - G(:,0:6) vec(0:6)   VS:1213-1217
+    std::vector<double> A(225), K1(225);
+    for (int k = 0; k < 225; k++) A[k] = cov_inv[k] / 1000;
+    for (int r = 0; r < 6; r++) for (int k = 0; k < 6; k++) A[r * DIM + k] += HTH[r * 6 + k];
+    vbh::inverse_pplu(A.data(), K1.data(), DIM);
+    for (int r = 0; r < DIM; r++)
+      for (int k = 0; k < 6; k++) { double sacc = 0; for (int j = 0; j < 6; j++) sacc += K1[r * DIM + j] * HTH[j * 6 + k]; G[r * DIM + k] = sacc; }
+    double vec[15], RtR[9], lg[3];
+    vbh::m3_Tmul(x_curr.R, x_prop.R, RtR);
+    vbh::so3_log(RtR, lg);
+    for (int k = 0; k < 3; k++) { vec[k] = lg[k]; vec[3 + k] = x_prop.p[k] - x_curr.p[k]; vec[6 + k] = x_prop.v[k] - x_curr.v[k]; vec[9 + k] = x_prop.bg[k] - x_curr.bg[k]; vec[12 + k] = x_prop.ba[k] - x_curr.ba[k]; }
+    double sol[15];
+    for (int r = 0; r < DIM; r++) {
+      double a = 0, b = 0;
+      for (int j = 0; j < 6; j++) { a += K1[r * DIM + j] * HTz[j]; b += G[r * DIM + j] * vec[j]; }
+      sol[r] = a + vec[r] - b;
+    }
+    double E[9], Rn[9];
+    vbh::so3_exp(sol, E);
+    vbh::m3_mul(x_curr.R, E, Rn);
+    std::memcpy(x_curr.R, Rn, sizeof(Rn));
+    for (int k = 0; k < 3; k++) { x_curr.p[k] += sol[3 + k]; x_curr.v[k] += sol[6 + k]; x_curr.bg[k] += sol[9 + k]; x_curr.ba[k] += sol[12 + k]; }
+    const double rot_add = vbh::norm3(sol), tra_add = vbh::norm3(sol + 3);
+    refind = false;                                                          // VS:1223-1234
+    if ((rot_add * 57.3 < 0.01) && (tra_add * 100 < 0.015)) { refind = true; converged_once = true; rematch_num++; }
+    if (iter == num_max_iter - 2 && !converged_once) refind = true;
+    if (rematch_num >= 2 || (iter == num_max_iter - 1)) {
+      std::vector<double> IG(225), Pn(225);
+      for (int r = 0; r < DIM; r++) for (int k = 0; k < DIM; k++) IG[r * DIM + k] = (r == k ? 1.0 : 0.0) - G[r * DIM + k];
+      vbh::mat_mul(IG.data(), P.data(), Pn.data(), DIM, DIM, DIM);
+      P = Pn;
+      break;
+    }
+  }
+  // map update VS:1238-1250: append the scan in the refined pose, re-sample on a 0.5 m grid
+  if (n > 0) hipLaunchKernelGGL(k_kd_append, dim3(nb), dim3(256), 0, c->stream, n, d_pts, pose_of(x_curr), c->d_kdtree[c->kd_cur] + (size_t)c->kd_n * 3);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int tot = c->kd_n + n;
+  {
+    std::vector<int> cnt(tot), first(tot);
+    int m = 0;
+    st = vba_scan_down_sampling_voxel(c, tot, c->d_kdtree[c->kd_cur], 0.5, c->d_kdtree[c->kd_cur ^ 1], cnt.data(), first.data(), &m);
+    if (st) return st;
+    c->kd_cur ^= 1; c->kd_n = m;
+  }
+  std::memcpy(state, &x_curr, sizeof(x_curr));
+  std::memcpy(cov, P.data(), 225 * sizeof(double));
+  if (iterations) *iterations = iters;
   return VBA_OK;
 }
 
