@@ -49,7 +49,8 @@ enum vba_status {
   VBA_ERR_TOO_FEW_VOXELS = 4,  /* Lidar_BA_Optimizer::only_residual "Too Less Voxel" exit(0), VM:399-403 */
   VBA_ERR_OPT_STATE = 5,       /* OctoTree::margi "Error: opt_state" exit(0), VM:1488-1492 */
   VBA_ERR_HIP = 6,
-  VBA_ERR_CAPACITY = 7
+  VBA_ERR_CAPACITY = 7,
+  VBA_ERR_IO = 8               /* file missing / malformed (read_lidarstate prints "not found" and exits, VH:271-275) */
 };
 
 typedef struct vba_ctx vba_ctx;
@@ -292,6 +293,21 @@ int vba_lm_begin(vba_ctx *ctx, const double *poses, int thd_num);
 int vba_lm_refresh_eigen(vba_ctx *ctx); /* device-side residual pass at the begin poses (re-creates eig/pcr_add state) */
 int vba_lm_iterate(vba_ctx *ctx, int *accepted, int *stop); /* NULL, NULL: enqueue only (no host synchronisation) */
 int vba_lm_end(vba_ctx *ctx, double *poses, double *hess, double *resis2);
+
+/* ------------------------------------------------------------------------------------------------
+ * Session-store formats either side of the path.  Host only, no context.
+ *   FileReaderWriter::save_pcd (VS:166-179): <session>/<count>.pcd, pcl::io::savePCDFileBinary of PointXYZI (x y z from the
+ *     scan's body-frame points, intensity 0); read back with pcl::io::loadPCDFile (VS:337-340).  vba_io_load_pcd reads
+ *     DATA binary and DATA ascii files with x y z [intensity] among their fields; *n_out is the point count also when
+ *     VBA_ERR_CAPACITY is returned (call with cap 0 to size the buffers).
+ *   FileReaderWriter::save_pose (VS:181-204) / read_lidarstate (VH:268-307): alidarState.txt, one line per scan:
+ *     t px py pz qx qy qz qw vx vy vz bgx bgy bgz bax bay baz gx gy gz v6[0..5], fixed notation, 6 decimals for t, 7 for the
+ *     rest; nothing is written for fewer than 100 scans (VS:183-184); the reader accepts 8-, 20- and 26-column lines.
+ *   states: n x 25 doubles (t, R row-major, p, v, bg, ba, g — the layout of vba_odom_*), v6: n x 6. */
+int vba_io_save_pcd(const char *path, int n, const double *xyz);
+int vba_io_load_pcd(const char *path, int cap, double *xyz, double *intensity /* may be NULL */, int *n_out);
+int vba_io_save_pose(const char *path, int n, const double *states, const double *v6);
+int vba_io_read_lidarstate(const char *path, int cap, double *states, double *v6 /* may be NULL */, int *n_out);
 
 #ifdef __cplusplus
 }

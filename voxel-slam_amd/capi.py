@@ -31,6 +31,7 @@ EXPORTS = [
     "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
     "vba_lm_begin", "vba_lm_refresh_eigen", "vba_lm_iterate", "vba_lm_end",
+    "vba_io_save_pcd", "vba_io_load_pcd", "vba_io_save_pose", "vba_io_read_lidarstate",
 ]
 
 
@@ -128,6 +129,45 @@ def imu_give_evaluate(imu, st1, st2, with_g=False, jac=True):
     if st:
         raise VbaError(st)
     return r.value, jtj, gg
+
+
+def _io_chk(st):
+    if st:
+        raise VbaError(st, load().vba_status_string(st).decode())
+
+
+def save_pcd(path, xyz):
+    """FileReaderWriter::save_pcd (voxelslam.cpp:166-179): binary PCD of PointXYZI, intensity 0."""
+    xyz = _c(xyz).reshape(-1, 3)
+    _io_chk(load().vba_io_save_pcd(os.fsencode(path), C.c_int(len(xyz)), _p(xyz)))
+
+
+def load_pcd(path):
+    """pcl::io::loadPCDFile as used by previous_map_read (voxelslam.cpp:337-340) -> (xyz [n,3], intensity [n])."""
+    n = C.c_int(0)
+    st = load().vba_io_load_pcd(os.fsencode(path), C.c_int(0), None, None, C.byref(n))
+    if st not in (0, 7):
+        _io_chk(st)
+    xyz = np.zeros((max(n.value, 1), 3)); inten = np.zeros(max(n.value, 1))
+    _io_chk(load().vba_io_load_pcd(os.fsencode(path), C.c_int(n.value), _p(xyz), _p(inten), C.byref(n)))
+    return xyz[:n.value], inten[:n.value]
+
+
+def save_pose(path, states, v6):
+    """FileReaderWriter::save_pose (voxelslam.cpp:181-204); writes nothing for fewer than 100 scans."""
+    states = _c(states).reshape(-1, 25); v6 = _c(v6).reshape(-1, 6)
+    _io_chk(load().vba_io_save_pose(os.fsencode(path), C.c_int(len(states)), _p(states), _p(v6)))
+
+
+def read_lidarstate(path):
+    """read_lidarstate (voxelslam.hpp:268-307) -> (states [n,25], v6 [n,6])."""
+    n = C.c_int(0)
+    st = load().vba_io_read_lidarstate(os.fsencode(path), C.c_int(0), None, None, C.byref(n))
+    if st not in (0, 7):
+        _io_chk(st)
+    states = np.zeros((max(n.value, 1), 25)); v6 = np.zeros((max(n.value, 1), 6))
+    _io_chk(load().vba_io_read_lidarstate(os.fsencode(path), C.c_int(n.value), _p(states), _p(v6), C.byref(n)))
+    return states[:n.value], v6[:n.value]
 
 
 class Context:

@@ -12,6 +12,7 @@
 #include "vba_kernels_gba.hpp"
 #include "vba_kernels_big.hpp"
 #include "vba_kernels_kd.hpp"
+#include "vba_io.hpp"
 #include <cstddef>
 #include "vba_hostmath.hpp"
 
@@ -383,6 +384,7 @@ const char *vba_status_string(int s) {
     case VBA_ERR_OPT_STATE: return "opt_state out of range (reference: exit)";
     case VBA_ERR_HIP: return "HIP runtime error";
     case VBA_ERR_CAPACITY: return "capacity exceeded";
+    case VBA_ERR_IO: return "file missing or malformed";
     default: return "unknown";
   }
 }
@@ -1750,5 +1752,154 @@ int vba_odom_lio_state_estimation(vba_ctx *c, int n, const double *pnt_body, con
 }
 
 int vba_map_dump_leaves(vba_ctx *c, double *out, int max_leaves) { return map_dump_leaves(c->map, c->stream, out, max_leaves, c->err); }
+
+// ---------------------------------------------------------------- session-store formats (vba_io.hpp), host only
+int vba_io_save_pcd(const char *path, int n, const double *xyz) {
+  if (!path || n < 0 || (n > 0 && !xyz)) return VBA_ERR_BAD_ARG;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return VBA_ERR_IO;
+  std::fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+                  "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n", n, n);
+  std::vector<float> rec((size_t)n * 4);
+  for (int i = 0; i < n; i++) {                                // save_pcd sets x, y, z only: intensity keeps PointXYZI's default 0 (VS:170-176)
+    rec[4 * (size_t)i] = (float)xyz[3 * (size_t)i]; rec[4 * (size_t)i + 1] = (float)xyz[3 * (size_t)i + 1];
+    rec[4 * (size_t)i + 2] = (float)xyz[3 * (size_t)i + 2]; rec[4 * (size_t)i + 3] = 0.f;
+  }
+  const size_t w = n > 0 ? std::fwrite(rec.data(), 16, (size_t)n, f) : 0;
+  const int bad = std::fclose(f);
+  return (w == (size_t)n && !bad) ? VBA_OK : VBA_ERR_IO;
+}
+
+int vba_io_load_pcd(const char *path, int cap, double *xyz, double *intensity, int *n_out) {
+  if (!path || !n_out || cap < 0 || (cap > 0 && !xyz)) return VBA_ERR_BAD_ARG;
+  *n_out = 0;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return VBA_ERR_IO;
+  struct Close { FILE *f; ~Close() { std::fclose(f); } } closer{f};
+  vba_io::PcdHeader h;
+  char line[1024];
+  while (h.data.empty()) {
+    if (!std::fgets(line, sizeof(line), f)) return VBA_ERR_IO;
+    std::istringstream ss(line);
+    std::string key, tok;
+    if (!(ss >> key) || key[0] == '#') continue;
+    if (key == "FIELDS" || key == "COLUMNS") while (ss >> tok) h.fields.push_back(tok);
+    else if (key == "SIZE") while (ss >> tok) h.size.push_back(std::atoi(tok.c_str()));
+    else if (key == "TYPE") while (ss >> tok) h.type.push_back(tok);
+    else if (key == "COUNT") while (ss >> tok) h.count.push_back(std::atoi(tok.c_str()));
+    else if (key == "WIDTH") ss >> h.width;
+    else if (key == "HEIGHT") ss >> h.height;
+    else if (key == "POINTS") ss >> h.points;
+    else if (key == "DATA") ss >> h.data;
+  }
+  const size_t nf = h.fields.size();
+  if (nf == 0 || h.size.size() != nf || h.type.size() != nf) return VBA_ERR_IO;
+  if (h.count.empty()) h.count.assign(nf, 1);
+  if (h.count.size() != nf) return VBA_ERR_IO;
+  if (h.points < 0) h.points = h.width * h.height;
+  if (h.points < 0) return VBA_ERR_IO;
+  int fx = -1, fy = -1, fz = -1, fi = -1;
+  std::vector<size_t> off(nf);
+  size_t stride = 0;
+  for (size_t k = 0; k < nf; k++) {
+    off[k] = stride; stride += (size_t)h.size[k] * (size_t)h.count[k];
+    if (h.fields[k] == "x") fx = (int)k; else if (h.fields[k] == "y") fy = (int)k; else if (h.fields[k] == "z") fz = (int)k;
+    else if (h.fields[k] == "intensity") fi = (int)k;
+  }
+  if (fx < 0 || fy < 0 || fz < 0) return VBA_ERR_IO;
+  *n_out = (int)h.points;
+  if (h.points > cap) return VBA_ERR_CAPACITY;                 // *n_out tells the caller what to allocate
+  auto scalar = [&](const unsigned char *p, size_t k) -> double {
+    const char t = h.type[k][0]; const int sz = h.size[k];
+    if (t == 'F') { if (sz == 4) { float v; std::memcpy(&v, p, 4); return v; } if (sz == 8) { double v; std::memcpy(&v, p, 8); return v; } }
+    if (t == 'U') { uint64_t v = 0; std::memcpy(&v, p, (size_t)sz); return (double)v; }              // little endian
+    if (t == 'I') { int64_t v = 0; std::memcpy(&v, p, (size_t)sz); const int sh = 64 - 8 * sz; return (double)((v << sh) >> sh); }
+    return 0.0;
+  };
+  if (h.data == "binary") {
+    std::vector<unsigned char> buf((size_t)h.points * stride);
+    if (h.points > 0 && std::fread(buf.data(), stride, (size_t)h.points, f) != (size_t)h.points) return VBA_ERR_IO;
+    for (long i = 0; i < h.points; i++) {
+      const unsigned char *r = buf.data() + (size_t)i * stride;
+      xyz[3 * i] = scalar(r + off[fx], fx); xyz[3 * i + 1] = scalar(r + off[fy], fy); xyz[3 * i + 2] = scalar(r + off[fz], fz);
+      if (intensity) intensity[i] = fi >= 0 ? scalar(r + off[fi], fi) : 0.0;
+    }
+  } else if (h.data == "ascii") {
+    for (long i = 0; i < h.points; i++) {
+      if (!std::fgets(line, sizeof(line), f)) return VBA_ERR_IO;
+      std::istringstream ss(line);
+      if (intensity) intensity[i] = 0.0;
+      for (size_t k = 0; k < nf; k++)
+        for (int cidx = 0; cidx < h.count[k]; cidx++) {
+          double v;
+          if (!(ss >> v)) return VBA_ERR_IO;
+          if (cidx) continue;
+          if ((int)k == fx) xyz[3 * i] = v; else if ((int)k == fy) xyz[3 * i + 1] = v; else if ((int)k == fz) xyz[3 * i + 2] = v;
+          else if ((int)k == fi && intensity) intensity[i] = v;
+        }
+    }
+  } else {
+    return VBA_ERR_IO;                                          // binary_compressed: never written by the reference (VS:178)
+  }
+  return VBA_OK;
+}
+
+int vba_io_save_pose(const char *path, int n, const double *states, const double *v6) {
+  if (!path || n < 0 || (n > 0 && (!states || !v6))) return VBA_ERR_BAD_ARG;
+  if (n < 100) return VBA_OK;                                   // VS:183-184: short sessions are not saved
+  FILE *f = std::fopen(path, "w");
+  if (!f) return VBA_ERR_IO;
+  for (int i = 0; i < n; i++) {
+    vbh::State x;
+    std::memcpy(&x, states + (size_t)i * 25, sizeof(x));
+    double q[4];
+    vba_io::quat_from_rot(x.R, q);
+    std::fprintf(f, "%.6f ", x.t);                              // fixed, precision 6; then precision 7 for the rest (VS:192-193)
+    std::fprintf(f, "%.7f %.7f %.7f ", x.p[0], x.p[1], x.p[2]);
+    std::fprintf(f, "%.7f %.7f %.7f %.7f", q[0], q[1], q[2], q[3]);
+    const double *grp[4] = {x.v, x.bg, x.ba, x.g};
+    for (int g = 0; g < 4; g++) std::fprintf(f, " %.7f %.7f %.7f", grp[g][0], grp[g][1], grp[g][2]);
+    for (int j = 0; j < 6; j++) std::fprintf(f, " %.7f", v6[(size_t)i * 6 + j]);
+    std::fprintf(f, "\n");
+  }
+  return std::fclose(f) ? VBA_ERR_IO : VBA_OK;
+}
+
+int vba_io_read_lidarstate(const char *path, int cap, double *states, double *v6, int *n_out) {
+  if (!path || !n_out || cap < 0 || (cap > 0 && !states)) return VBA_ERR_BAD_ARG;
+  *n_out = 0;
+  FILE *f = std::fopen(path, "r");
+  if (!f) return VBA_ERR_IO;                                    // the reference prints "not found" and exits (VH:271-275)
+  struct Close { FILE *f; ~Close() { std::fclose(f); } } closer{f};
+  std::vector<char> line(1 << 16);
+  int n = 0;
+  while (std::fgets(line.data(), (int)line.size(), f)) {
+    std::vector<double> nums;
+    char *p = line.data();
+    for (;;) {
+      char *e = nullptr;
+      const double v = std::strtod(p, &e);
+      if (e == p) break;
+      nums.push_back(v); p = e;
+    }
+    if (nums.size() < 8) { if (nums.empty()) continue; return VBA_ERR_IO; }
+    if (n < cap) {
+      vbh::State x;
+      std::memset(&x, 0, sizeof(x));
+      x.g[2] = -9.8;                                            // lines without g: the reference leaves IMUST::g unset (TL:188-197); gravity here
+      x.t = nums[0];
+      for (int k = 0; k < 3; k++) x.p[k] = nums[1 + k];
+      const double q[4] = {nums[4], nums[5], nums[6], nums[7]};
+      vba_io::rot_from_quat(q, x.R);
+      if (nums.size() >= 20)
+        for (int k = 0; k < 3; k++) { x.v[k] = nums[8 + k]; x.bg[k] = nums[11 + k]; x.ba[k] = nums[14 + k]; x.g[k] = nums[17 + k]; }
+      std::memcpy(states + (size_t)n * 25, &x, sizeof(x));
+      if (v6) for (int k = 0; k < 6; k++) v6[(size_t)n * 6 + k] = nums.size() >= 26 ? nums[20 + k] : 0.0;
+    }
+    n++;
+  }
+  *n_out = n;
+  return n > cap ? VBA_ERR_CAPACITY : VBA_OK;
+}
 
 }  // extern "C"
