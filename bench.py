@@ -324,8 +324,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     local_rank = local_rank % torch.cuda.device_count()     # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VBA_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL all_reduce per LM iteration) with a single rank, to measure
+    # what the collective adds on a one-GPU box
+    dist_on = world > 1 or os.environ.get("VBA_BENCH_FORCE_DIST", "") not in ("", "0")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("VBA_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only to rehearse on one card
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -339,7 +344,7 @@ def main():
     opt = capi.options_from_workload(wl, stream=stream)
     opt.device = local_rank
     ctx = capi.Context(opt)
-    if world > 1:
+    if dist_on:
         ctx.set_shard(rank, world)        # K1 keeps only the points whose root voxel falls in this rank's bucket range
 
         ctx.set_torch_allreduce(torch, dist)   # collective issued on the context's stream (RCCL all_reduce, SUM)
@@ -372,7 +377,7 @@ def main():
     ctx.timing_enable(False)
     V_local = ctx.size()
     vt = torch.tensor([V_local], device="cuda", dtype=torch.int64)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(vt)
     V_total = int(vt.item())
     n_points = sum(len(p) for p in scans["points"])
@@ -393,16 +398,16 @@ def main():
     ctx.timing_enable(True)
     ctx.timing_select("residual")
     ctx.timing_reset()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -485,7 +490,7 @@ def main():
             "config": {"workload": "%s: Hesai-32-like synthetic scans, %d pts/scan, W=%d, voxel %.2f m; %d planar voxels "
                                    "(%.1f occupied frames/voxel), lidar-only LM (Lidar_BA_Optimizer)"
                                    % (wl.name, wl.n_pts, W, wl.voxel_size, V_total, occ),
-                       "parallelism": "voxel-bucket shard x%d + all-reduce of [H|g|r]" % world if world > 1 else "single GPU"},
+                       "parallelism": "voxel-bucket shard x%d + all-reduce of [H|g|r]" % world if dist_on else "single GPU"},
             "roofline": roof,
             "roofline_residual_pass_scene_x16": scaled,
             "local_mapping_step": lms,
@@ -500,7 +505,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, scans, poses0)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

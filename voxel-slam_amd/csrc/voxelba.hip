@@ -67,6 +67,8 @@ struct vba_ctx {
   vba_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   int rank = 0, n_ranks = 1;
+  bool force_collective = std::getenv("VBA_FORCE_COLLECTIVE") != nullptr;   // rehearsal: run the exchange step with one rank
+  bool collective() const { return allreduce && (n_ranks > 1 || force_collective); }
 
   // timing
   bool timing = false;
@@ -281,7 +283,7 @@ int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head,
     span_end(c, "reduce", s2);
     HIPCHK(c, hipGetLastError());
   }
-  if (c->allreduce && c->n_ranks > 1) {
+  if (c->collective()) {
     int rc = c->allreduce(c->allreduce_user, c->d_out, (size_t)nout, c->stream);
     if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
   }
@@ -303,7 +305,7 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
     span_end(c, "reduce", s2);
     HIPCHK(c, hipGetLastError());
   }
-  if (c->allreduce && c->n_ranks > 1) {
+  if (c->collective()) {
     int rc = c->allreduce(c->allreduce_user, d_scalar_out, 1, c->stream);
     if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
   }
@@ -603,7 +605,7 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   // too (speculating that the step is accepted) and [H | g | r] is all-reduced once: its r (the sum of the eigenvalues the
   // residual pass just stored) is the trial residual the accept test needs, and on acceptance H is already the next
   // iteration's Hessian; on a reject the solve keeps using its saved copy (`raw`), exactly as VM:443 skips divide_thread.
-  const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
+  const int copy_raw = c->collective() ? 1 : 0;
   int st = VBA_OK;
   static const bool no_fuse = getenv("VBA_NO_FUSED_UPDATE") != nullptr;   // diagnostic: accept/reject always as its own kernel
   if (!(copy_raw && c->lm.have_hess)) {
@@ -687,7 +689,7 @@ int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (hess) {
     int st = ensure_pin(c, 65536 + (size_t)n * n + 1024);
     if (st) return st;
-    const double *src = (c->allreduce && c->n_ranks > 1) ? c->d_raw : c->d_out;    // *hess = Hess before gauge fixing (VM:446)
+    const double *src = c->collective() ? c->d_raw : c->d_out;    // *hess = Hess before gauge fixing (VM:446)
     st = tiles_to_full(c, src);
     if (st) return st;
     HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, c->d_full, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -790,7 +792,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const double *xt_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, xt));
   const int *run_hess = reinterpret_cast<const int *>(base + offsetof(LmDev, run_hess));
   const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
-  const int copy_raw = (c->allreduce && c->n_ranks > 1) ? 1 : 0;
+  const int copy_raw = c->collective() ? 1 : 0;
   const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16 + (size_t)F * 225) * sizeof(double);
   {
     static bool attr_set = false;      // W = 10 with gravity: 88 KB
