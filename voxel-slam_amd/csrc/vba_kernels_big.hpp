@@ -26,6 +26,7 @@ struct BigView {
   double *eval, *evec, *pcr;   // [3][capV], [9][capV], [10][capV]
   double *poses;    // [W][12]
   double *H, *g, *r;   // dense (6W)^2, 6W, 1
+  int *eidx;           // [V][W] entry of (voxel, frame) or -1 (k_big_syrk operand staging)
 };
 
 __device__ __forceinline__ void big_cluster_tf(const double *c, const double *R, double *o) { cluster_transform_dev(c, R, o); }
@@ -132,24 +133,72 @@ __global__ void k_big_slot(BigView b) {
     for (int c = 0; c < 6; c++) unsafeAtomicAdd(Hd + (size_t)a * n6 + c, Eb[a][c]);
 }
 
-// Hessian pass, part 2: entry i against every entry j of its voxel
-__global__ void k_big_pairs(BigView b) {
+// Hessian pass, part 2: H += sum_v G_v^T C_v G_v as a blocked SYRK.  (An earlier version gave every entry a thread that
+// added its 6x6 products against the voxel's other entries with f64 atomics: ~1e8 atomics per pass at W = 60, 1.4 ms — L2
+// atomic throughput, not address contention: 32 private copies of H did not change it.)
+// Workgroup = one pair (bi <= bj) of 8-frame tiles (48 x 48 outputs, a 3 x 3 patch per thread, accumulators in registers) x
+// one slice of the voxels.  Per chunk of 16 voxels the 48 k-rows (voxel, m = g1 | g2 | h) x 48 columns of both sides are
+// staged in LDS through the (voxel, frame) -> entry map; the i side carries the weights c_m.  A chunk with no entry in one
+// of the two tiles is skipped (sparse windows).  The slice results are added to H with one atomic per output (and its
+// mirror when bi != bj).
+constexpr int BIG_TF = 8, BIG_TC = 6 * BIG_TF, BIG_VC = 16, BIG_KR = 3 * BIG_VC;
+
+__global__ void k_big_eidx(BigView b) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= b.E) return;
+  if (e < b.E) b.eidx[(size_t)b.evox[e] * b.W + b.efr[e]] = e;
+}
+
+__global__ __launch_bounds__(256) void k_big_syrk(BigView b, int nt, int nslice) {
+  __shared__ double A[BIG_KR][BIG_TC], B[BIG_KR][BIG_TC];
+  // block pair from the linear index (row-major upper triangle)
+  int bi = 0, rem = blockIdx.x;
+  while (rem >= nt - bi) { rem -= nt - bi; bi++; }
+  const int bj = bi + rem;
+  const int t = threadIdx.x, pr = t >> 4, pc = t & 15;
   const size_t ce = (size_t)b.capE, cv = (size_t)b.capV;
-  const int v = b.evox[e], fi = b.efr[e], n6 = 6 * b.W;
-  const double l0 = b.eval[v], l1 = b.eval[cv + v], l2 = b.eval[2 * cv + v], NN = b.pcr[9 * cv + v];
-  const double c1 = 2.0 / (l0 - l1), c2 = 2.0 / (l0 - l2), c3 = -2.0 / NN / NN;                                    // VM:201, 264-268
-  double a1[6], a2[6], a3[6];
-  for (int d = 0; d < 6; d++) { a1[d] = c1 * b.gv[(size_t)d * ce + e]; a2[d] = c2 * b.gv[(size_t)(6 + d) * ce + e]; a3[d] = c3 * b.gv[(size_t)(12 + d) * ce + e]; }
-  for (int j = b.vptr[v]; j < b.vptr[v + 1]; j++) {
-    const int fj = b.efr[j];
-    double b1[6], b2[6], b3[6];
-    for (int d = 0; d < 6; d++) { b1[d] = b.gv[(size_t)d * ce + j]; b2[d] = b.gv[(size_t)(6 + d) * ce + j]; b3[d] = b.gv[(size_t)(12 + d) * ce + j]; }
-    double *Hb = b.H + (size_t)(6 * fi) * n6 + 6 * fj;
-    for (int a = 0; a < 6; a++)
-      for (int c = 0; c < 6; c++) unsafeAtomicAdd(Hb + (size_t)a * n6 + c, a1[a] * b1[c] + a2[a] * b2[c] + a3[a] * b3[c]);
+  const int nchunk = (b.V + BIG_VC - 1) / BIG_VC;
+  const int per = (nchunk + nslice - 1) / nslice, c0 = blockIdx.y * per, c1 = (c0 + per < nchunk) ? c0 + per : nchunk;
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  // fill role of this thread: side (0 = i side, scaled), voxel of the chunk, frame of the tile
+  const int side = t >> 7, vl = (t & 127) >> 3, fl = t & 7;
+  const int f = (side ? bj : bi) * BIG_TF + fl;
+  for (int ch = c0; ch < c1; ch++) {
+    const int v = ch * BIG_VC + vl;
+    int e = -1;
+    if (v < b.V && f < b.W) e = b.eidx[(size_t)v * b.W + f];
+    const int any_i = __syncthreads_or(side == 0 && e >= 0), any_j = __syncthreads_or(side == 1 && e >= 0);
+    if (!any_i || !any_j) continue;                                   // uniform: the barriers above are reached by every thread
+    double w[3] = {1.0, 1.0, 1.0};
+    if (e >= 0 && side == 0) {
+      const double l0 = b.eval[v], l1 = b.eval[cv + v], l2 = b.eval[2 * cv + v], NN = b.pcr[9 * cv + v];
+      w[0] = 2.0 / (l0 - l1); w[1] = 2.0 / (l0 - l2); w[2] = -2.0 / NN / NN;                                      // VM:201, 264-268
+    }
+    double (*S)[BIG_TC] = side ? B : A;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+      for (int d = 0; d < 6; d++) S[vl * 3 + m][fl * 6 + d] = e >= 0 ? w[m] * b.gv[(size_t)(6 * m + d) * ce + e] : 0.0;
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < BIG_KR; k++) {
+      const double a0 = A[k][3 * pr], a1 = A[k][3 * pr + 1], a2 = A[k][3 * pr + 2];
+      const double b0 = B[k][3 * pc], b1 = B[k][3 * pc + 1], b2 = B[k][3 * pc + 2];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
+      acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
+      acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
+    }
+    // (the next chunk's barriers order these reads against its LDS writes)
   }
+  const int n6 = 6 * b.W;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int r = bi * BIG_TC + 3 * pr + i, c = bj * BIG_TC + 3 * pc + j;
+      if (r >= n6 || c >= n6 || acc[i][j] == 0.0) continue;
+      unsafeAtomicAdd(b.H + (size_t)r * n6 + c, acc[i][j]);
+      if (bi != bj) unsafeAtomicAdd(b.H + (size_t)c * n6 + r, acc[i][j]);
+    }
 }
 
 // ---------------------------------------------------------------- octree build with (node, frame) hashed body clusters
@@ -512,6 +561,7 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
   BIGCHK(al((void **)&b.poses, (size_t)W * 12 * 8));
   const size_t n6 = (size_t)6 * W;
   BIGCHK(al((void **)&b.H, n6 * n6 * 8)); BIGCHK(al((void **)&b.g, n6 * 8)); BIGCHK(al((void **)&b.r, 8));
+
   s.NP = (int)((n6 + 7) / 8 * 8); s.ld = (int)((s.NP + 63) / 64 * 64);
   BIGCHK(al((void **)&s.d_Ab, (size_t)(s.NP + 1) * s.ld * 8)); BIGCHK(al((void **)&s.d_Tb, (size_t)(s.NP + 1) * 8 * 8)); BIGCHK(al((void **)&s.d_ord, n6 * 4));
   BIGCHK(hipMemsetAsync(s.d_fill, 0, (size_t)b.capV * 4, st));
@@ -534,6 +584,12 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
     hipLaunchKernelGGL(k_gbab_voxels, dim3((nn + 255) / 256), bk, 0, st, g, b);
     BIGCHK(hipGetLastError());
   }
+  BIGCHK(al((void **)&b.eidx, (size_t)b.capV * W * 4));
+  BIGCHK(hipMemsetAsync(b.eidx, 0xFF, (size_t)b.capV * W * 4, st));
+  if (V > 0 && E > 0) {
+    hipLaunchKernelGGL(k_big_eidx, dim3((E + 255) / 256), bk, 0, st, b);
+    BIGCHK(hipGetLastError());
+  }
   return VBA_OK;
 }
 
@@ -545,7 +601,11 @@ inline int big_hessian(BigStore &s, hipStream_t st, const double *poses, double 
   BIGCHK(hipMemsetAsync(b.H, 0, n6 * n6 * 8, st)); BIGCHK(hipMemsetAsync(b.g, 0, n6 * 8, st)); BIGCHK(hipMemsetAsync(b.r, 0, 8, st));
   if (b.E > 0) {
     hipLaunchKernelGGL(k_big_slot, dim3((b.E + 127) / 128), dim3(128), 0, st, b);
-    hipLaunchKernelGGL(k_big_pairs, dim3((b.E + 127) / 128), dim3(128), 0, st, b);
+    const int nt = (b.W + BIG_TF - 1) / BIG_TF, npair = nt * (nt + 1) / 2, nchunk = (b.V + BIG_VC - 1) / BIG_VC;
+    int nslice = (2048 + npair - 1) / npair;
+    if (nslice > nchunk) nslice = nchunk;
+    if (nslice < 1) nslice = 1;
+    hipLaunchKernelGGL(k_big_syrk, dim3(npair, nslice), dim3(256), 0, st, b, nt, nslice);
     BIGCHK(hipGetLastError());
   }
   BIGCHK(hipStreamSynchronize(st));
