@@ -27,6 +27,7 @@ struct BigView {
   double *poses;    // [W][12]
   double *H, *g, *r;   // dense (6W)^2, 6W, 1
   int *eidx;           // [V][W] entry of (voxel, frame) or -1 (k_big_syrk operand staging)
+  double *es;          // [27][capE] diagonal-block remainder E (21 upper) + gradient (6) of an entry, summed per frame by k_big_diag
 };
 
 __device__ __forceinline__ void big_cluster_tf(const double *c, const double *R, double *o) { cluster_transform_dev(c, R, o); }
@@ -96,7 +97,7 @@ __global__ void k_big_slot(BigView b) {
   double gj[6];
   gj[0] = 2.0 * (wy * a02 - wz * a01) * inn; gj[1] = 2.0 * (wz * a00 - wx * a02) * inn; gj[2] = 2.0 * (wx * a01 - wy * a00) * inn;
   gj[3] = 2.0 * d0 * k0 * inn; gj[4] = 2.0 * d0 * k1 * inn; gj[5] = 2.0 * d0 * k2 * inn;                          // VM:235-236
-  for (int k = 0; k < 6; k++) unsafeAtomicAdd(b.g + 6 * fi + k, gj[k]);
+  for (int k = 0; k < 6; k++) b.es[(size_t)(21 + k) * ce + e] = gj[k];
   double g1[6], g2[6], hh[6];
   {
     const double bx1 = pa10 + s1 * vx, by1 = pa11 + s1 * vy, bz1 = pa12 + s1 * vz;
@@ -128,9 +129,40 @@ __global__ void k_big_slot(BigView b) {
   const double qq[3] = {qx, qy, qz}, kk[3] = {k0, k1, k2};
   for (int a = 0; a < 3; a++)
     for (int c = 0; c < 3; c++) { Eb[a][3 + c] = e2 * qq[a] * kk[c]; Eb[3 + c][a] = Eb[a][3 + c]; Eb[3 + a][3 + c] = e2 * n * kk[a] * kk[c]; }
-  double *Hd = b.H + (size_t)(6 * fi) * n6 + 6 * fi;
+  int idx = 0;
   for (int a = 0; a < 6; a++)
-    for (int c = 0; c < 6; c++) unsafeAtomicAdd(Hd + (size_t)a * n6 + c, Eb[a][c]);
+    for (int c = a; c < 6; c++) b.es[(size_t)(idx++) * ce + e] = Eb[a][c];
+}
+// One workgroup per frame sums the E blocks and gradients of the frame's entries (fixed order, no atomics) and adds them to
+// the diagonal block of H / to g.  (Per-entry atomics put E / W entries on each of the 42 W addresses: 0.26 ms at W = 60.)
+__global__ __launch_bounds__(256) void k_big_diag(BigView b) {
+  __shared__ double red[4][27];
+  const int f = blockIdx.x, tid = threadIdx.x, n6 = 6 * b.W;
+  const size_t ce = (size_t)b.capE;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = 0.0;
+  for (int v = tid; v < b.V; v += 256) {
+    const int e = b.eidx[(size_t)v * b.W + f];
+    if (e < 0) continue;
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] += b.es[(size_t)k * ce + e];
+  }
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = wave_sum(acc[k]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 27; k++) red[tid >> 6][k] = acc[k];
+  __syncthreads();
+  if (tid < 27) {
+    const double val = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid >= 21) { b.g[6 * f + tid - 21] += val; return; }
+    int a = 0, rem = tid;
+    while (rem >= 6 - a) { rem -= 6 - a; a++; }
+    const int c = a + rem;
+    b.H[(size_t)(6 * f + a) * n6 + 6 * f + c] += val;
+    if (a != c) b.H[(size_t)(6 * f + c) * n6 + 6 * f + a] += val;
+  }
 }
 
 // Hessian pass, part 2: H += sum_v G_v^T C_v G_v as a blocked SYRK.  (An earlier version gave every entry a thread that
@@ -239,8 +271,12 @@ __global__ void k_gbab_keys(GbaBigView g, GbaParams P) {
   const unsigned long long key = pack_key(kx, ky, kz);
   unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & g.hmask;
   for (unsigned int probe = 0; probe <= g.hmask; probe++) {
-    const unsigned long long old = atomicCAS(&g.hkeys[h], KEY_EMPTY, key);
-    if (old == KEY_EMPTY || old == key) break;
+    unsigned long long old = g.hkeys[h];                               // almost every point finds its root present: read before the CAS
+    if (old == key) break;
+    if (old == KEY_EMPTY) {
+      old = atomicCAS(&g.hkeys[h], KEY_EMPTY, key);
+      if (old == KEY_EMPTY || old == key) break;
+    }
     h = (h + 1) & g.hmask;
   }
   g.pnode[p] = (int)h;
@@ -266,22 +302,47 @@ __global__ void k_gbab_rootid(GbaBigView g) {
   const int s = g.pnode[p];
   if (s >= 0) g.pnode[p] = g.hvals[s];
 }
-__global__ void k_gbab_accum(GbaBigView g) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= g.npts) return;
-  const int id = g.pnode[p];
-  if (id < 0) return;
+// (LDS pre-aggregation per (node, frame) as k_gba_accum; the global (node, frame) table is probed once per occupied LDS entry)
+__global__ __launch_bounds__(256) void k_gbab_accum(GbaBigView g) {
+  __shared__ unsigned long long tkey[512];
+  __shared__ unsigned int tslot[512];
+  __shared__ double tacc[20][512];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < 512; t += 256) tkey[t] = ~0ull;
+  for (int t = tid; t < 20 * 512; t += 256) (&tacc[0][0])[t] = 0.0;
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + tid;
   const size_t n = (size_t)g.npts, cp = (size_t)g.cap, ct = (size_t)g.emask + 1;
-  atomic_cluster_add(g.nadd + id, cp, g.pw[p], g.pw[n + p], g.pw[2 * n + p]);
-  const unsigned long long key = ((unsigned long long)(unsigned int)id << 20) | (unsigned int)g.pframe[p];
-  unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & g.emask;
-  for (unsigned int probe = 0; probe <= g.emask; probe++) {
-    const unsigned long long old = atomicCAS(&g.ekeys[h], KEY_EMPTY, key);
-    if (old == KEY_EMPTY) { atomicAdd(&g.nexi[id], 1); break; }       // a new (node, frame) pair: one more keyframe sees the node
-    if (old == key) break;
-    h = (h + 1) & g.emask;
+  if (p < g.npts) {
+    const int id = g.pnode[p];
+    if (id >= 0) {
+      const unsigned int e = gba_lds_claim(tkey, ((unsigned long long)(unsigned int)id << 20) | (unsigned int)g.pframe[p]);
+      gba_lds_add(tacc, e, g.pl[3 * (size_t)p], g.pl[3 * (size_t)p + 1], g.pl[3 * (size_t)p + 2], g.pw[p], g.pw[n + p], g.pw[2 * n + p]);
+    }
   }
-  atomic_cluster_add(g.ecl + h, ct, g.pl[3 * (size_t)p], g.pl[3 * (size_t)p + 1], g.pl[3 * (size_t)p + 2]);
+  __syncthreads();
+  for (int e = tid; e < 512; e += 256) {
+    const unsigned long long key = tkey[e];
+    if (key == ~0ull) continue;
+    unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & g.emask;
+    for (unsigned int probe = 0; probe <= g.emask; probe++) {
+      const unsigned long long old = atomicCAS(&g.ekeys[h], KEY_EMPTY, key);
+      if (old == KEY_EMPTY) { atomicAdd(&g.nexi[(int)(key >> 20)], 1); break; }   // a new (node, frame) pair: one more keyframe sees the node
+      if (old == key) break;
+      h = (h + 1) & g.emask;
+    }
+    tslot[e] = h;
+  }
+  __syncthreads();
+  for (int t = tid; t < 20 * 512; t += 256) {
+    const int k = t >> 9, e = t & 511;
+    const unsigned long long key = tkey[e];
+    if (key == ~0ull) continue;
+    const double v = tacc[k][e];
+    if (v == 0.0) continue;
+    if (k < 10) unsafeAtomicAdd(g.nadd + (size_t)k * cp + (size_t)(key >> 20), v);
+    else unsafeAtomicAdd(g.ecl + (size_t)(k - 10) * ct + tslot[e], v);
+  }
 }
 __global__ void k_gbab_decide(GbaBigView g, GbaParams P, int layer) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,7 +638,7 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
   }
   b.E = E; b.capE = E > 0 ? E : 1;
   BIGCHK(al((void **)&b.efr, (size_t)b.capE * 4)); BIGCHK(al((void **)&b.evox, (size_t)b.capE * 4));
-  BIGCHK(al((void **)&b.ecl, (size_t)b.capE * 10 * 8)); BIGCHK(al((void **)&b.gv, (size_t)b.capE * 18 * 8));
+  BIGCHK(al((void **)&b.ecl, (size_t)b.capE * 10 * 8)); BIGCHK(al((void **)&b.gv, (size_t)b.capE * 18 * 8)); BIGCHK(al((void **)&b.es, (size_t)b.capE * 27 * 8));
   if (V > 0) {
     const int nn = s.h_cnt[GCNT_NODES] < g.cap ? s.h_cnt[GCNT_NODES] : g.cap;
     hipLaunchKernelGGL(k_gbab_fill, dim3((ecap + 255) / 256), bk, 0, st, g, b, s.d_fill);
@@ -606,6 +667,7 @@ inline int big_hessian(BigStore &s, hipStream_t st, const double *poses, double 
     if (nslice > nchunk) nslice = nchunk;
     if (nslice < 1) nslice = 1;
     hipLaunchKernelGGL(k_big_syrk, dim3(npair, nslice), dim3(256), 0, st, b, nt, nslice);
+    hipLaunchKernelGGL(k_big_diag, dim3(b.W), dim3(256), 0, st, b);   // after the SYRK atomics on H (stream order)
     BIGCHK(hipGetLastError());
   }
   BIGCHK(hipStreamSynchronize(st));

@@ -55,8 +55,12 @@ __global__ void k_gba_keys(GbaView g, GbaParams P) {
   unsigned long long hsh = key * 0x9E3779B97F4A7C15ull;
   unsigned int h = (unsigned int)(hsh >> 32) & g.hmask;
   for (unsigned int probe = 0; probe <= g.hmask; probe++) {
-    const unsigned long long old = atomicCAS(&g.hkeys[h], KEY_EMPTY, key);
-    if (old == KEY_EMPTY || old == key) break;
+    unsigned long long old = g.hkeys[h];                               // almost every point finds its root present: read before the CAS
+    if (old == key) break;
+    if (old == KEY_EMPTY) {
+      old = atomicCAS(&g.hkeys[h], KEY_EMPTY, key);
+      if (old == KEY_EMPTY || old == key) break;
+    }
     h = (h + 1) & g.hmask;
   }
   g.pnode[p] = (int)h;     // slot for now; k_gba_rootid turns it into the node id
@@ -88,16 +92,55 @@ __global__ void k_gba_rootid(GbaView g) {
   if (s >= 0) g.pnode[p] = g.hvals[s];
 }
 
-__global__ void k_gba_accum(GbaView g) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= g.npts) return;
-  const int id = g.pnode[p];
-  if (id < 0) return;
+// 256 consecutive points of a keyframe fall into a handful of nodes: the 20 cluster scalars are first summed per
+// (node, frame) in an LDS hash table of the workgroup (as k_ins_accum, vba_kernels_map.hpp) and only its occupied entries
+// go to HBM as f64 atomics — at layer 0 every point of a window lands in ~10^2 root voxels and per-point global atomics
+// serialise on them.
+__device__ __forceinline__ unsigned int gba_lds_claim(unsigned long long *tkey, unsigned long long key) {
+  unsigned int e = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 55);
+  while (true) {
+    const unsigned long long old = atomicCAS(&tkey[e], ~0ull, key);
+    if (old == ~0ull || old == key) break;
+    e = (e + 1) & 511;
+  }
+  return e;
+}
+__device__ __forceinline__ void gba_lds_add(double (*tacc)[512], unsigned int e, double x, double y, double z, double wx, double wy, double wz) {
+  unsafeAtomicAdd(&tacc[0][e], wx * wx); unsafeAtomicAdd(&tacc[1][e], wx * wy); unsafeAtomicAdd(&tacc[2][e], wx * wz);
+  unsafeAtomicAdd(&tacc[3][e], wy * wy); unsafeAtomicAdd(&tacc[4][e], wy * wz); unsafeAtomicAdd(&tacc[5][e], wz * wz);
+  unsafeAtomicAdd(&tacc[6][e], wx); unsafeAtomicAdd(&tacc[7][e], wy); unsafeAtomicAdd(&tacc[8][e], wz); unsafeAtomicAdd(&tacc[9][e], 1.0);
+  unsafeAtomicAdd(&tacc[10][e], x * x); unsafeAtomicAdd(&tacc[11][e], x * y); unsafeAtomicAdd(&tacc[12][e], x * z);
+  unsafeAtomicAdd(&tacc[13][e], y * y); unsafeAtomicAdd(&tacc[14][e], y * z); unsafeAtomicAdd(&tacc[15][e], z * z);
+  unsafeAtomicAdd(&tacc[16][e], x); unsafeAtomicAdd(&tacc[17][e], y); unsafeAtomicAdd(&tacc[18][e], z); unsafeAtomicAdd(&tacc[19][e], 1.0);
+}
+
+__global__ __launch_bounds__(256) void k_gba_accum(GbaView g) {
+  __shared__ unsigned long long tkey[512];
+  __shared__ double tacc[20][512];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < 512; t += 256) tkey[t] = ~0ull;
+  for (int t = tid; t < 20 * 512; t += 256) (&tacc[0][0])[t] = 0.0;
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + tid;
   const size_t n = (size_t)g.npts, cp = (size_t)g.cap;
-  const double wx = g.pw[p], wy = g.pw[n + p], wz = g.pw[2 * n + p];
-  atomic_cluster_add(g.nadd + id, cp, wx, wy, wz);
-  const double x = g.pl[3 * (size_t)p], y = g.pl[3 * (size_t)p + 1], z = g.pl[3 * (size_t)p + 2];
-  atomic_cluster_add(g.nlc + (size_t)g.pframe[p] * cp + id, cp * (size_t)g.W, x, y, z);
+  if (p < g.npts) {
+    const int id = g.pnode[p];
+    if (id >= 0) {
+      const unsigned int e = gba_lds_claim(tkey, ((unsigned long long)(unsigned int)id << 20) | (unsigned int)g.pframe[p]);
+      gba_lds_add(tacc, e, g.pl[3 * (size_t)p], g.pl[3 * (size_t)p + 1], g.pl[3 * (size_t)p + 2], g.pw[p], g.pw[n + p], g.pw[2 * n + p]);
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < 20 * 512; t += 256) {
+    const int k = t >> 9, e = t & 511;
+    const unsigned long long key = tkey[e];
+    if (key == ~0ull) continue;
+    const double v = tacc[k][e];
+    if (v == 0.0) continue;
+    const size_t id = (size_t)(key >> 20), f = (size_t)(key & 0xFFFFFull);
+    if (k < 10) unsafeAtomicAdd(g.nadd + (size_t)k * cp + id, v);
+    else unsafeAtomicAdd(g.nlc + ((size_t)(k - 10) * g.W + f) * cp + id, v);
+  }
 }
 
 __global__ void k_gba_decide(GbaView g, GbaParams P, int layer) {
