@@ -547,12 +547,27 @@ __global__ __launch_bounds__(256) void k_bigl_update(double *__restrict__ Ab, co
 struct BigStore {
   BigView b{};
   GbaBigView g{};
-  std::vector<void *> bufs;
+  // Device memory comes from an arena of large chunks that survives across builds (reset() rewinds it): hipMalloc / hipFree
+  // of ~40 buffers per build, some of them 10^8 bytes, cost more than the kernels of a top-level window.
+  struct Chunk { char *base; size_t size, used; };
+  std::vector<Chunk> chunks;
+  hipError_t arena(void **p, size_t bytes) {
+    bytes = (bytes ? bytes : 8) + 255 & ~(size_t)255;
+    for (Chunk &ck : chunks)
+      if (ck.size - ck.used >= bytes) { *p = ck.base + ck.used; ck.used += bytes; return hipSuccess; }
+    Chunk ck{nullptr, bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20), 0};
+    hipError_t e = hipMalloc((void **)&ck.base, ck.size);
+    if (e != hipSuccess) return e;
+    ck.used = bytes; *p = ck.base;
+    chunks.push_back(ck);
+    return hipSuccess;
+  }
+  void reset() { for (Chunk &ck : chunks) ck.used = 0; b = BigView(); g = GbaBigView(); }
   int *h_cnt = nullptr;
   int *d_vcnt = nullptr, *d_fill = nullptr;
   double *d_Ab = nullptr, *d_Tb = nullptr; int *d_ord = nullptr;   // dense solver (allocated by big_build)
   int NP = 0, ld = 0;
-  void release() { for (void *p : bufs) hipFree(p); bufs.clear(); if (h_cnt) hipHostFree(h_cnt); h_cnt = nullptr; b = BigView(); g = GbaBigView(); }
+  void release() { for (Chunk &ck : chunks) hipFree(ck.base); chunks.clear(); if (h_cnt) hipHostFree(h_cnt); h_cnt = nullptr; b = BigView(); g = GbaBigView(); }
 };
 
 #define BIGCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return VBA_ERR_HIP; } } while (0)
@@ -560,10 +575,10 @@ struct BigStore {
 // Builds the octree of `W` keyframes and the sparse factor store (everything is re-allocated per call: the top-level BA
 // runs once per loop closure).  pl: device pointer to the local points [n][3].
 inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, const double *d_pl, const double *poses, const GbaParams &P, std::string &err) {
-  s.release();
+  s.reset();
   const int n = offsets[W];
-  auto al = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) s.bufs.push_back(*p); return e; };
-  BIGCHK(hipHostMalloc((void **)&s.h_cnt, GCNT_N * sizeof(int), hipHostMallocDefault));
+  auto al = [&](void **p, size_t bytes) { return s.arena(p, bytes); };
+  if (!s.h_cnt) BIGCHK(hipHostMalloc((void **)&s.h_cnt, GCNT_N * sizeof(int), hipHostMallocDefault));
   GbaBigView &g = s.g;
   g.W = W; g.npts = n; g.pl = d_pl;
   unsigned int hcap = 1u << 16; while (hcap < 2u * (unsigned)n && hcap < (1u << 28)) hcap <<= 1;
@@ -583,7 +598,7 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
     g.cap = cap;
     void *tmp[9];
     size_t sz[9] = {10 * cp * 8, 3 * cp * 8, 3 * cp * 8, 9 * cp * 8, cp * 4, cp * 4, cp * 4, cp * 4, cp};
-    for (int k = 0; k < 9; k++) { if (hipMalloc(&tmp[k], sz[k]) != hipSuccess) { err = "octree node storage"; return VBA_ERR_HIP; } }
+    for (int k = 0; k < 9; k++) { if (s.arena(&tmp[k], sz[k]) != hipSuccess) { err = "octree node storage"; return VBA_ERR_HIP; } }
     g.nadd = (double *)tmp[0]; g.ncenter = (double *)tmp[1]; g.neval = (double *)tmp[2]; g.nevec = (double *)tmp[3]; g.nql = (float *)tmp[4];
     g.nchild = (int *)tmp[5]; g.nfac = (int *)tmp[6]; g.nexi = (int *)tmp[7]; g.nlayer = (signed char *)tmp[8];
     BIGCHK(hipMemsetAsync(g.cnt, 0, GCNT_N * sizeof(int), st));
@@ -607,9 +622,9 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
     BIGCHK(hipStreamSynchronize(st));
     BIGCHK(hipMemcpyAsync(s.h_cnt, g.cnt, GCNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
     BIGCHK(hipStreamSynchronize(st));
-    if (s.h_cnt[GCNT_OVERFLOW] == 2) { for (int k = 0; k < 9; k++) hipFree(tmp[k]); err = "keyframe point outside the 21-bit voxel index range"; return VBA_ERR_CAPACITY; }
-    if (!s.h_cnt[GCNT_OVERFLOW]) { for (int k = 0; k < 9; k++) s.bufs.push_back(tmp[k]); break; }
-    for (int k = 0; k < 9; k++) hipFree(tmp[k]);
+    if (s.h_cnt[GCNT_OVERFLOW] == 2) { err = "keyframe point outside the 21-bit voxel index range"; return VBA_ERR_CAPACITY; }
+    if (!s.h_cnt[GCNT_OVERFLOW]) break;
+    // (the undersized node arrays stay in the arena until the next build rewinds it)
     cap *= 2;
     if (attempt == 9) { err = "octree node capacity"; return VBA_ERR_CAPACITY; }
   }

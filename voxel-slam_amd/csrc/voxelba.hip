@@ -100,6 +100,7 @@ struct vba_ctx {
   size_t kd_cap = 0; int kd_n = 0, kd_cur = 0;
   double *d_refpts = nullptr;     // submap cloud staging (HBA_add_edge)
   size_t refpts_doubles = 0;
+  double *d_hba_all = nullptr; size_t hba_all_doubles = 0;   // vba_hba_global: keyframe clouds + submap clouds, kept across calls
 
   void set_error(const std::string &s) { err = s; }
 };
@@ -438,6 +439,7 @@ void vba_destroy(vba_ctx *c) {
   map_free(c->map);
   c->gba.free_all();
   c->big.release();
+  if (c->d_hba_all) hipFree(c->d_hba_all);
   for (int i = 0; i < 2; i++) if (c->d_kdtree[i]) hipFree(c->d_kdtree[i]);
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
@@ -1283,6 +1285,11 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
   const int W = wdsize, n6 = 6 * W, n = offsets[W];
   *n_edges = 0;
   if (n_log) *n_log = 0;
+  static const bool want_times = getenv("VBA_HBA_TIMES") != nullptr;      // diagnostic: wall-clock split of the call on stderr
+  double t_ph[5] = {0, 0, 0, 0, 0};
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = want_times ? now() : 0.0;
+  auto lap = [&](int k) { if (want_times) { hipStreamSynchronize(c->stream); const double t = now(); t_ph[k] += t - t_mark; t_mark = t; } };
   // the keyframe clouds stay in HBM for the whole call (every outer iteration re-cuts them with the current poses)
   if ((size_t)n * 3 > c->refpts_doubles) {
     if (c->d_refpts) hipFree(c->d_refpts);
@@ -1293,6 +1300,7 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
   if (n > 0) HIPCHK(c, hipMemcpyAsync(d_pl, pnt_local, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
   GbaParams P = gba_params(c, gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array);
   std::vector<double> hess((size_t)n6 * n6, 0.0);
+  lap(0);
   const int up = 4;                                                       // VS:2866
   int converge_flag = 0;
   double converge_thre = 0.05;
@@ -1304,13 +1312,16 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
     if (!big) {
       st = gba_build_into_store(c, W, offsets, d_pl, poses, P);
       if (st) return st;
+      lap(1);
       st = vba_lidar_ba_damping_iter(c, poses, hess.data(), resis, up, thread_num, &is_converge);
     } else {
       st = big_build(c->big, c->stream, W, offsets, d_pl, poses, P, c->err);
       if (st) return st;
+      lap(1);
       st = big_damping_iter(c, W, poses, hess, resis, up, thread_num, &is_converge);
     }
     if (st) return st;
+    lap(2);
     if (resis_log && n_log) { resis_log[2 * *n_log] = resis[0]; resis_log[2 * *n_log + 1] = resis[1]; (*n_log)++; }
     if ((std::fabs(resis[0] - resis[1]) / resis[0] < converge_thre && is_converge) || (iterCnt == max_iter - 2 && converge_flag == 0)) {
       converge_thre = 0.01;                                               // VS:2903-2915
@@ -1338,6 +1349,7 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
       for (int k = 0; k < 6; k++) o[14 + k] = v6[k];
     }
   *n_edges = ne;
+  lap(3);
   if (cloud_out) {                                                        // VS:2954-2989
     *n_cloud = 0;
     if (n > 0) {
@@ -1359,6 +1371,9 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
       if (st) return st;
     }
   }
+  lap(4);
+  if (want_times)
+    std::fprintf(stderr, "[hba_add_edge W=%d n=%d] upload %.0f  build %.0f  LM %.0f  edges %.0f  cloud %.0f us\n", W, n, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4]);
   return VBA_OK;
 }
 
@@ -1375,27 +1390,38 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
       (offsets[n_kf] > 0 && !pnt_local))
     return VBA_ERR_BAD_ARG;
   *n_edges1 = 0; *n_edges2 = 0;
-  std::vector<int> sub_first;                       // global id of every submap's first keyframe
-  std::vector<std::vector<double>> sub_cloud;
+  std::vector<int> sub_first, sub_n;                // global id of every submap's first keyframe, points of its cloud
   std::vector<double> edges((size_t)(wdsize * (wdsize - 1) / 2 + 1) * 20);
-  // the keyframe clouds go to HBM once (the stride-5 windows overlap: every keyframe is used twice)
-  double *d_all = nullptr;
+  // the keyframe clouds go to HBM once (the stride-5 windows overlap: every keyframe is used twice) and the submap clouds
+  // never leave it: every window's down-sampled cloud is written behind the previous one and the top-level BA reads them there
   const size_t n_all = (size_t)offsets[n_kf];
-  if (n_all > 0) {
-    HIPCHK(c, hipMalloc((void **)&d_all, n_all * 3 * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream);
-    if (e != hipSuccess) { hipFree(d_all); c->set_error(hipGetErrorString(e)); return VBA_ERR_HIP; }
+  size_t n_sub_cap = 0, n_win_max = 0;
+  for (int start = 0; start + wdsize <= n_kf; start += mgsize) {
+    const size_t nw = (size_t)(offsets[start + wdsize] - offsets[start]);
+    n_sub_cap += nw; if (nw > n_win_max) n_win_max = nw;
   }
-  struct Free { double *p; ~Free() { if (p) hipFree(p); } } free_all{d_all};
+  const size_t need = (n_all + n_sub_cap) * 3 + 64;
+  if (need > c->hba_all_doubles) {
+    if (c->d_hba_all) hipFree(c->d_hba_all);
+    c->d_hba_all = nullptr; c->hba_all_doubles = 0;
+    HIPCHK(c, hipMalloc((void **)&c->d_hba_all, need * sizeof(double)));
+    c->hba_all_doubles = need;
+  }
+  double *d_all = c->d_hba_all, *d_sub = c->d_hba_all + n_all * 3;
+  if (n_all > 0) HIPCHK(c, hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  std::vector<int> ccnt(n_win_max > 0 ? n_win_max : 1);
+  size_t sub_off = 0;
+  static const bool want_times = getenv("VBA_HBA_TIMES") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_g0 = want_times ? (hipStreamSynchronize(c->stream), now()) : 0.0;
+  double t_g1 = 0;
   for (int start = 0; start + wdsize <= n_kf; start += mgsize) {
     std::vector<int> off(wdsize + 1);
     for (int i = 0; i <= wdsize; i++) off[i] = offsets[start + i] - offsets[start];
     std::vector<double> xs(poses_x0 + (size_t)start * 12, poses_x0 + (size_t)(start + wdsize) * 12);
-    std::vector<double> cloud((size_t)(off[wdsize] > 0 ? off[wdsize] : 1) * 3);
-    std::vector<int> ccnt(off[wdsize] > 0 ? off[wdsize] : 1);
     int ne = 0, nc = 0;
     int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
-                              gba_eigen_value_array, 1, 2, edges.data(), &ne, cloud.data(), ccnt.data(), &nc, nullptr, nullptr);
+                              gba_eigen_value_array, 1, 2, edges.data(), &ne, d_sub + sub_off * 3, ccnt.data(), &nc, nullptr, nullptr);
     if (st) return st;
     for (int e = 0; e < ne; e++) {
       if (*n_edges1 >= cap1) return VBA_ERR_CAPACITY;
@@ -1404,21 +1430,20 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
       o[0] += start; o[1] += start;
       (*n_edges1)++;
     }
-    cloud.resize((size_t)nc * 3);
     sub_first.push_back(start);
-    sub_cloud.push_back(std::move(cloud));
+    sub_n.push_back(nc);
+    sub_off += (size_t)nc;
   }
   const int ns = (int)sub_first.size();
+  if (want_times) t_g1 = now();
+  struct Report { bool on; double t0, *t1; decltype(now) *clk; ~Report() { if (on) std::fprintf(stderr, "[hba_global] windows %.0f us, top %.0f us (after the upload)\n", *t1 - t0, (*clk)() - *t1); } } report{want_times, t_g0, &t_g1, &now};
   if (ns >= 2) {
     std::vector<int> off(ns + 1, 0);
-    for (int i = 0; i < ns; i++) off[i + 1] = off[i] + (int)(sub_cloud[i].size() / 3);
-    std::vector<double> pts((size_t)(off[ns] > 0 ? off[ns] : 1) * 3), xs((size_t)ns * 12), e2((size_t)(ns * (ns - 1) / 2 + 1) * 20);
-    for (int i = 0; i < ns; i++) {
-      std::memcpy(&pts[(size_t)off[i] * 3], sub_cloud[i].data(), sub_cloud[i].size() * sizeof(double));
-      std::memcpy(&xs[(size_t)i * 12], poses_now + (size_t)sub_first[i] * 12, 12 * sizeof(double));
-    }
+    for (int i = 0; i < ns; i++) off[i + 1] = off[i] + sub_n[i];
+    std::vector<double> xs((size_t)ns * 12), e2((size_t)(ns * (ns - 1) / 2 + 1) * 20);
+    for (int i = 0; i < ns; i++) std::memcpy(&xs[(size_t)i * 12], poses_now + (size_t)sub_first[i] * 12, 12 * sizeof(double));
     int ne = 0;
-    int st = vba_hba_add_edge(c, ns, off.data(), pts.data(), xs.data(), gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array, total_max_iter, 5,
+    int st = vba_hba_add_edge(c, ns, off.data(), d_sub, xs.data(), gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array, total_max_iter, 5,
                               e2.data(), &ne, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (st) return st;
     for (int e = 0; e < ne; e++) {
