@@ -285,7 +285,7 @@ def hba_window(capi, torch, reps=10, cpu=True):
     return res
 
 
-def odometry_update(capi, torch, wl, scans, reps=10):
+def odometry_update(capi, torch, wl, scans, reps=10, cpu=True):
     """lio_state_estimation (voxelslam.cpp:962-1098) of one 200k-point scan against the full-window map: device point loop
     (world covariance, hash lookup + octant descent, 3-sigma gate, 34 weighted sums) x <= 4 EKF iterations, host 15x15 algebra."""
     from voxel_slam_amd import synth
@@ -311,7 +311,33 @@ def odometry_update(capi, torch, wl, scans, reps=10):
         ok, st, cv = ctx.lio_state_estimation(pts, var_b, state, cov)
     dt = (time.perf_counter() - t0) / reps
     ctx.close()
-    return {"ms_per_scan": 1e3 * dt, "points": int(len(pts)), "converged": bool(ok), "what": "points + covariances uploaded per call"}
+    res = {"ms_per_scan": 1e3 * dt, "points": int(len(pts)), "converged": bool(ok), "what": "points + covariances uploaded per call"}
+    # the initialisation odometry (lio_state_estimation_kdtree, voxelslam.cpp:1102-1252): exact 5-NN plane fit against the
+    # point-cloud map, EKF, map update (append + 0.5 m re-sampling); a short sequence of scans, the first one seeds the map
+    ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+    seq = [p[::10].astype(np.float32).astype(np.float64) for p in scans["points"][:4]]     # 20k-point scans (the CPU port is a brute-force search too)
+    def run_kd(step):
+        cv = np.eye(15) * 1e-4
+        tt, its, tree = 0.0, 0, 0
+        for i, p in enumerate(seq):
+            s0 = np.zeros(25); s0[1:10] = scans["R_gt"][i].ravel(); s0[10:13] = scans["p_gt"][i] + (0.01 if i else 0.0); s0[22:25] = [0, 0, -9.8]
+            t1 = time.perf_counter()
+            it, _, cv2 = step(p, s0, cv)
+            if i:
+                tt += time.perf_counter() - t1; its += it
+        return tt / (len(seq) - 1), its
+    run_kd(ctx.lio_state_estimation_kdtree); ctx.lib.vba_odom_kdtree_reset(ctx.h)
+    t_kd, its_kd = run_kd(ctx.lio_state_estimation_kdtree)
+    res["kdtree_variant"] = {"ms_per_scan": 1e3 * t_kd, "points": int(len(seq[0])), "map_points": int(ctx.kdtree_size()), "ekf_iterations": its_kd,
+                             "what": "brute-force exact 5-NN on the device + EKF + map re-sampling, scan uploaded per call"}
+    ctx.close()
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        ko = oracle_api.KdOdom()
+        t_cpu, _ = run_kd(ko.lio_state_estimation)
+        res["kdtree_variant"]["cpu_port_ms_per_scan"] = 1e3 * t_cpu     # the oracle searches by brute force too (the reference uses a FLANN kd-tree): not a speed-up claim
+    return res
 
 
 def main():
@@ -491,7 +517,7 @@ def main():
         liv = li_variant(ctx, capi, wl, scans, poses0)
         lms = local_mapping_step(capi, torch, wl, scans, poses0)
         hba = hba_window(capi, torch, cpu=not args.no_cpu_baseline)
-        odo = odometry_update(capi, torch, wl, scans)
+        odo = odometry_update(capi, torch, wl, scans, cpu=not args.no_cpu_baseline)
     roof["cold"] = cold
 
     if rank == 0:

@@ -101,3 +101,25 @@ def test_lio_state_estimation_kdtree_parity(oracle):
             assert np.abs(tg - to).max() < 1e-4
         cov_g, cov_o = cov_g2, cov_o2
     ctx.close()
+
+
+def test_kdtree_odometry_edge_cases():
+    """Empty scan, a map below the 100-point threshold (the scan only seeds it, VS:1105-1118) and pl_tree->clear()."""
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    ctx = capi.Context(capi.options_from_workload(synth.CONFIGS["room20k_w4"]))
+    state = np.zeros(25); state[1:10] = np.eye(3).ravel(); state[22:25] = [0, 0, -9.8]
+    cov = np.eye(15) * 1e-4
+    rng = np.random.default_rng(0)
+    it, st, cv = ctx.lio_state_estimation_kdtree(np.zeros((0, 3)), state, cov)
+    assert it == 0 and ctx.kdtree_size() == 0
+    pts = rng.uniform(-5, 5, (60, 3)).astype(np.float32).astype(np.float64)
+    it, st, cv = ctx.lio_state_estimation_kdtree(pts, state, cov)          # 0 < 100: seeds
+    assert it == 0 and ctx.kdtree_size() == 60
+    np.testing.assert_array_equal(ctx.kdtree_points(), pts)                # identity pose: the float points themselves
+    it, st, cv = ctx.lio_state_estimation_kdtree(pts, state, cov)          # 60 < 100: appended, still no estimation
+    assert it == 0 and ctx.kdtree_size() == 120
+    np.testing.assert_array_equal(st, state); np.testing.assert_array_equal(cv, cov)
+    ctx._chk(ctx.lib.vba_odom_kdtree_reset(ctx.h))
+    assert ctx.kdtree_size() == 0
+    ctx.close()
