@@ -262,6 +262,55 @@ inline std::vector<GbaEdge> HBA_add_edge(Context &ctx, std::vector<IMUST> &xs, c
   return out;
 }
 
+// VOXEL_SLAM::lio_state_estimation_kdtree(pptr) VS:1102-1252: x_curr (state + cov) in/out, the point-cloud map (pl_tree) lives in
+// the context.  Returns the number of EKF iterations (0 while the map is only being seeded).
+inline int lio_state_estimation_kdtree(Context &ctx, const std::vector<pointVar> &pvec, IMUST &x_curr) {
+  const int n = (int)pvec.size();
+  std::vector<double> p((size_t)n * 3);
+  for (int i = 0; i < n; i++) { p[3 * i] = (float)pvec[i].pnt[0]; p[3 * i + 1] = (float)pvec[i].pnt[1]; p[3 * i + 2] = (float)pvec[i].pnt[2]; }   // PointType is float (VS:1143-1146)
+  int iters = 0;
+  check(ctx.get(), vba_odom_lio_state_estimation_kdtree(ctx.get(), n, p.data(), &x_curr.t, x_curr.cov, &iters));
+  return iters;
+}
+
+// FileReaderWriter::save_pcd / save_pose (VS:166-204), pcl::io::loadPCDFile (VS:340), read_lidarstate (VH:268-307)
+inline void save_pcd(const std::vector<pointVar> &pvec, int count, const std::string &savename) {
+  std::vector<double> p(pvec.size() * 3);
+  for (size_t i = 0; i < pvec.size(); i++) std::memcpy(&p[3 * i], pvec[i].pnt, 24);
+  const std::string path = savename + "/" + std::to_string(count) + ".pcd";
+  if (vba_io_save_pcd(path.c_str(), (int)pvec.size(), p.data())) throw std::runtime_error("save_pcd: " + path);
+}
+inline std::vector<XYZ> load_pcd(const std::string &path) {
+  int n = 0;
+  int st = vba_io_load_pcd(path.c_str(), 0, nullptr, nullptr, &n);
+  if (st != VBA_OK && st != VBA_ERR_CAPACITY) throw std::runtime_error("load_pcd: " + path);
+  std::vector<double> p((size_t)(n > 0 ? n : 1) * 3);
+  if (vba_io_load_pcd(path.c_str(), n, p.data(), nullptr, &n)) throw std::runtime_error("load_pcd: " + path);
+  std::vector<XYZ> out(n);
+  for (int i = 0; i < n; i++) out[i] = XYZ{(float)p[3 * i], (float)p[3 * i + 1], (float)p[3 * i + 2]};
+  return out;
+}
+struct ScanPoseRec { IMUST x; double v6[6]; };   // ScanPose (LR:17-27) without the point pointer
+inline void save_pose(const std::vector<ScanPoseRec> &bbuf, const std::string &path) {
+  std::vector<double> st(bbuf.size() * 25), v6(bbuf.size() * 6);
+  for (size_t i = 0; i < bbuf.size(); i++) { std::memcpy(&st[25 * i], &bbuf[i].x.t, 200); std::memcpy(&v6[6 * i], bbuf[i].v6, 48); }
+  if (vba_io_save_pose(path.c_str(), (int)bbuf.size(), st.data(), v6.data())) throw std::runtime_error("save_pose: " + path);
+}
+inline std::vector<ScanPoseRec> read_lidarstate(const std::string &filename) {
+  int n = 0;
+  int st = vba_io_read_lidarstate(filename.c_str(), 0, nullptr, nullptr, &n);
+  if (st != VBA_OK && st != VBA_ERR_CAPACITY) throw std::runtime_error("read_lidarstate: " + filename);   // the reference exits (VH:271-275)
+  std::vector<double> s((size_t)(n > 0 ? n : 1) * 25), v6((size_t)(n > 0 ? n : 1) * 6);
+  if (vba_io_read_lidarstate(filename.c_str(), n, s.data(), v6.data(), &n)) throw std::runtime_error("read_lidarstate: " + filename);
+  std::vector<ScanPoseRec> out(n);
+  for (int i = 0; i < n; i++) {
+    std::memcpy(&out[i].x.t, &s[25 * (size_t)i], 200); std::memcpy(out[i].v6, &v6[6 * (size_t)i], 48);
+    for (int k = 0; k < 225; k++) out[i].x.cov[k] = 0.0;
+    for (int k = 0; k < 15; k++) out[i].x.cov[16 * k] = k < 9 ? 1e-4 : 1e-5;       // IMUST::setZero (TL:188-197)
+  }
+  return out;
+}
+
 #ifdef VBA_ADAPTER_HAVE_EIGEN
 // Eigen-typed conveniences so reference call sites keep their argument types (Eigen is column-major: converted here).
 inline void to_rowmajor3(const Eigen::Matrix3d &M, double *r) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[3 * i + j] = M(i, j); }
