@@ -2,8 +2,8 @@
 // matches every scan point against a point-cloud map through pcl::KdTreeFLANN::nearestKSearch (5 exact nearest neighbours,
 // squared L2 on float x, y, z), fits a plane to the five by least squares and runs the same iterated EKF as the voxel-map
 // odometry.  The map here holds at most a few 10^4 points (it is re-sampled on a 0.5 m grid after every scan), so the
-// exact 5-NN is a tiled brute-force scan: one thread per scan point, the map streamed through LDS 256 points at a time,
-// the five best kept sorted in registers — no tree, no traversal divergence.
+// exact 5-NN is a tiled brute-force scan: one thread per (scan point, map slice), the slice streamed through LDS 256 points at
+// a time, the five best kept sorted in registers, the slices merged by a second kernel — no tree, no traversal divergence.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,9 +61,12 @@ __device__ __forceinline__ void kd_lstsq_5x3(double A[5][3], double b[5], double
   for (int k = 0; k < 3; k++) x[perm[k]] = y[k];
 }
 
-// refind pass (VS:1156-1196): plane = (unit normal, distance) per scan point, distance < 0 = rejected
+// refind pass (VS:1156-1196), stage 1: the five nearest map points of every scan point WITHIN ONE SLICE of the map
+// (gridDim.y slices: one thread per scan point alone leaves three quarters of the chip idle at 20k-point scans).  A candidate
+// is the 64-bit word (float distance bits << 32 | index): positive floats order like their bit patterns, so comparing the
+// words orders by distance and, at equal distance, by index — the order a sequential scan with strict `<` produces.
 __global__ __launch_bounds__(256) void k_kd_match(int n, const double *__restrict__ pts, KdPose X, int m, const double *__restrict__ tree,
-                                                  double *__restrict__ planes /*[n][4]*/) {
+                                                  unsigned long long *__restrict__ cand /*[slices][n][5]*/) {
   __shared__ float tx[256], ty[256], tz[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float qx = 0, qy = 0, qz = 0;
@@ -75,12 +78,14 @@ __global__ __launch_bounds__(256) void k_kd_match(int n, const double *__restric
   }
   float bd0 = 3.4e38f, bd1 = 3.4e38f, bd2 = 3.4e38f, bd3 = 3.4e38f, bd4 = 3.4e38f;
   int bi0 = -1, bi1 = -1, bi2 = -1, bi3 = -1, bi4 = -1;
-  for (int base = 0; base < m; base += 256) {
+  const int ntile = (m + 255) / 256, per = (ntile + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int lo = (int)blockIdx.y * per * 256, hi = (lo + per * 256 < m) ? lo + per * 256 : m;
+  for (int base = lo; base < hi; base += 256) {
     const int j = base + threadIdx.x;
     __syncthreads();
-    if (j < m) { tx[threadIdx.x] = (float)tree[3 * (size_t)j]; ty[threadIdx.x] = (float)tree[3 * (size_t)j + 1]; tz[threadIdx.x] = (float)tree[3 * (size_t)j + 2]; }
+    if (j < hi) { tx[threadIdx.x] = (float)tree[3 * (size_t)j]; ty[threadIdx.x] = (float)tree[3 * (size_t)j + 1]; tz[threadIdx.x] = (float)tree[3 * (size_t)j + 2]; }
     __syncthreads();
-    const int cnt = (m - base < 256) ? m - base : 256;
+    const int cnt = (hi - base < 256) ? hi - base : 256;
     for (int k = 0; k < cnt; k++) {
       const float dx = qx - tx[k], dy = qy - ty[k], dz = qz - tz[k];
       float d = dx * dx; d += dy * dy; d += dz * dz;       // FLANN L2_Simple accumulates in float, x then y then z
@@ -97,16 +102,47 @@ __global__ __launch_bounds__(256) void k_kd_match(int n, const double *__restric
     }
   }
   if (i >= n) return;
-  const int bi[5] = {bi0, bi1, bi2, bi3, bi4};
+  unsigned long long *o = cand + ((size_t)blockIdx.y * n + i) * 5;
+  o[0] = ((unsigned long long)__float_as_uint(bd0) << 32) | (unsigned int)bi0;
+  o[1] = ((unsigned long long)__float_as_uint(bd1) << 32) | (unsigned int)bi1;
+  o[2] = ((unsigned long long)__float_as_uint(bd2) << 32) | (unsigned int)bi2;
+  o[3] = ((unsigned long long)__float_as_uint(bd3) << 32) | (unsigned int)bi3;
+  o[4] = ((unsigned long long)__float_as_uint(bd4) << 32) | (unsigned int)bi4;
+}
+
+// stage 2: merge the slices' candidates, fit the plane (VS:1166-1190): (unit normal, distance) per scan point, distance < 0 = rejected
+__global__ __launch_bounds__(256) void k_kd_fit(int n, int slices, const unsigned long long *__restrict__ cand, const double *__restrict__ tree,
+                                                double *__restrict__ planes /*[n][4]*/) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long b0 = ~0ull, b1 = ~0ull, b2 = ~0ull, b3 = ~0ull, b4 = ~0ull;
+  for (int s = 0; s < slices; s++) {
+    const unsigned long long *c = cand + ((size_t)s * n + i) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const unsigned long long key = c[k];
+      if ((unsigned int)key == 0xFFFFFFFFu) continue;       // unfilled slot
+      if (key < b4) {
+        if (key < b3) { b4 = b3;
+          if (key < b2) { b3 = b2;
+            if (key < b1) { b2 = b1;
+              if (key < b0) { b1 = b0; b0 = key; } else b1 = key;
+            } else b2 = key;
+          } else b3 = key;
+        } else b4 = key;
+      }
+    }
+  }
+  const unsigned long long bk[5] = {b0, b1, b2, b3, b4};
   double A[5][3], Aw[5][3], b[5];
   for (int k = 0; k < 5; k++) {
-    const int id = bi[k] < 0 ? 0 : bi[k];
-    for (int c = 0; c < 3; c++) { A[k][c] = (double)(float)tree[3 * (size_t)id + c]; Aw[k][c] = A[k][c]; }
+    const size_t id = (bk[k] == ~0ull) ? 0 : (size_t)(unsigned int)bk[k];
+    for (int c = 0; c < 3; c++) { A[k][c] = (double)(float)tree[3 * id + c]; Aw[k][c] = A[k][c]; }
     b[k] = -1.0;
   }
   double dir[3];
   kd_lstsq_5x3(Aw, b, dir);
-  bool bad = bi4 < 0;
+  bool bad = b4 == ~0ull;
   for (int k = 0; k < 5; k++) if (fabs(dir[0] * A[k][0] + dir[1] * A[k][1] + dir[2] * A[k][2] + 1.0) > 0.1) bad = true;     // VS:1174-1185
   double *o = planes + 4 * (size_t)i;
   if (bad || !(dir[0] == dir[0])) { o[0] = o[1] = o[2] = 0.0; o[3] = -1.0; return; }

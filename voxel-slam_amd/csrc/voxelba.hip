@@ -1068,9 +1068,11 @@ int vba_odom_lio_state_estimation_kdtree(vba_ctx *c, int n, const double *pnt_bo
   if (n < 0 || (n > 0 && !pnt_body) || !state || !cov) return VBA_ERR_BAD_ARG;
   if (iterations) *iterations = 0;
   const int DIM = VBA_DIM, nb = (n + 255) / 256;
-  int st = ensure_stage(c, ((size_t)n * 7 + (size_t)nb * 28 + 64) * sizeof(double));
+  const int kd_slices = nb >= 512 ? 1 : (nb >= 128 ? 4 : 8);               // enough workgroups to cover the chip
+  int st = ensure_stage(c, ((size_t)n * 7 + (size_t)nb * 28 + (size_t)kd_slices * n * 5 + 64) * sizeof(double));
   if (st) return st;
   double *d_pts = (double *)c->d_stage, *d_pl = d_pts + (size_t)n * 3, *d_part = d_pl + (size_t)n * 4;
+  unsigned long long *d_cand = (unsigned long long *)(d_part + (size_t)nb * 28);
   if (n > 0) HIPCHK(c, hipMemcpyAsync(d_pts, pnt_body, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
   vbh::State x_curr, x_prop;
   std::memcpy(&x_curr, state, sizeof(x_curr));
@@ -1098,7 +1100,10 @@ int vba_odom_lio_state_estimation_kdtree(vba_ctx *c, int n, const double *pnt_bo
     double s28[28];
     std::memset(s28, 0, sizeof(s28));
     if (n > 0) {
-      if (refind) hipLaunchKernelGGL(k_kd_match, dim3(nb), dim3(256), 0, c->stream, n, d_pts, X, c->kd_n, c->d_kdtree[c->kd_cur], d_pl);
+      if (refind) {
+        hipLaunchKernelGGL(k_kd_match, dim3(nb, kd_slices), dim3(256), 0, c->stream, n, d_pts, X, c->kd_n, c->d_kdtree[c->kd_cur], d_cand);
+        hipLaunchKernelGGL(k_kd_fit, dim3(nb), dim3(256), 0, c->stream, n, kd_slices, d_cand, c->d_kdtree[c->kd_cur], d_pl);
+      }
       hipLaunchKernelGGL(k_kd_accum, dim3(nb), dim3(256), 0, c->stream, n, d_pts, X, d_pl, d_part);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));
