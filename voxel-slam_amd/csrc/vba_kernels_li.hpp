@@ -436,4 +436,14 @@ __global__ __launch_bounds__(64) void k_li_update(LmDev *s, LiDev *li, double *_
   s->run_hess = (accept && !nstop) ? 1 : 0;
 }
 
+// gathers up to 8 device arrays into one block (one D2H copy instead of one per array)
+struct PackSegs { int n; const double *src[8]; size_t off[8], len[8]; };
+__global__ void k_pack_segments(PackSegs p, double *__restrict__ dst) {
+  const int s = blockIdx.y;
+  if (s >= p.n) return;
+  const double *src = p.src[s];
+  double *d = dst + p.off[s];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.len[s]; i += (size_t)gridDim.x * blockDim.x) d[i] = src[i];
+}
+
 }  // namespace vba
