@@ -45,7 +45,7 @@ __host__ __device__ inline long long key_axis(double pw, double voxel_size) {
   return (long long)loc;
 }
 
-enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_N };
+enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_SNAP, CNT_N };
 
 struct MapParams {
   int W, max_layer, max_points, thread_num;
@@ -282,9 +282,12 @@ __device__ __forceinline__ bool in_scope(const MapView &m, const MapParams &P, i
 }
 
 // One thread per node of layer L: leaf logic of OctoTree::recut VM:1399-1450.
+// The grid covers the node CAPACITY; the live range is the node count snapshotted on the device before the launch
+// (CNT_SNAP) — nodes created by this launch's own splits must not be visited by it, and reading the count back to size
+// the grid cost one ~18 us host round trip per level.
 __global__ void k_recut_leaf(MapView m, MapParams P, int L, int multi, int epoch) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  const int nn = m.cnt[CNT_SNAP] < m.cap ? m.cnt[CNT_SNAP] : m.cap;
   if (id >= nn) return;
   if (m.nlayer[id] != L || m.nstate[id] != 0) return;
   if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;   // VS:1693-1694
@@ -1056,6 +1059,7 @@ inline int map_stage(MapStore &s, size_t bytes, std::string &err) {
   return VBA_OK;
 }
 __global__ void k_set_counter(int *cnt, int which, int val) { cnt[which] = val; }
+__global__ void k_copy_counter(int *cnt, int from, int to) { cnt[to] = cnt[from]; }
 inline int map_set_counter(MapStore &s, hipStream_t st, int which, int val, std::string &err) {   // stream-ordered, no host sync
   hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, which, val);
   MAPCHK(hipGetLastError());
@@ -1169,20 +1173,22 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
     const MapParams P = map_params(s);
     int max_n = 0;
     for (int i = 0; i < win_count; i++) if (s.npts[s.mp[i]] > max_n) max_n = s.npts[s.mp[i]];
-    for (int L = 0; L <= s.opt.max_layer; L++) {
-      s.epoch++;
-      // node count can grow by 8 per split of the previous level: launch over the capacity-bounded upper estimate
-      r = map_read_counters(s, st, err);
-      if (r) return r;
-      const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
-      if (nn == 0) break;
-      hipLaunchKernelGGL(k_recut_leaf, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
-      if (L < s.opt.max_layer) {
-        if (max_n > 0 && win_count > 0)
-          hipLaunchKernelGGL(k_recut_points, dim3((max_n + 255) / 256, win_count), dim3(256), 0, st, s.v, P, win_count, s.epoch, s.have_var ? 1 : 0);
-        if (s.h_cnt[CNT_FIX] > 0)
-          hipLaunchKernelGGL(k_recut_fixpts, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v, P, s.epoch, L + 1);
+    const int grid_nodes = (s.v.cap + 255) / 256;
+    if (s.h_cnt[CNT_NODES] > 0) {
+      for (int L = 0; L <= s.opt.max_layer; L++) {
+        s.epoch++;
+        hipLaunchKernelGGL(k_copy_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_NODES, (int)CNT_SNAP);
+        hipLaunchKernelGGL(k_recut_leaf, dim3(grid_nodes), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
+        if (L < s.opt.max_layer) {
+          if (max_n > 0 && win_count > 0)
+            hipLaunchKernelGGL(k_recut_points, dim3((max_n + 255) / 256, win_count), dim3(256), 0, st, s.v, P, win_count, s.epoch, s.have_var ? 1 : 0);
+          if (s.h_cnt[CNT_FIX] > 0)
+            hipLaunchKernelGGL(k_recut_fixpts, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v, P, s.epoch, L + 1);
+        }
       }
+      // tras_opt pass 1 rides in the same submission: one counter read-back serves the overflow check and the factor count
+      r = map_set_counter(s, st, CNT_FACTORS, 0, err); if (r) return r;
+      hipLaunchKernelGGL(k_extract_count, dim3(grid_nodes), dim3(256), 0, st, s.v, P, multi ? 1 : 0);
     }
     MAPCHK(hipGetLastError());
     r = map_read_counters(s, st, err);
@@ -1192,14 +1198,7 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
     if (s.h_cnt[CNT_NODES] > s.v.cap) { r = map_set_counter(s, st, CNT_NODES, s.v.cap, err); if (r) return r; }
     if (attempt == 7) { err = "voxel map node capacity exceeded during recut"; return VBA_ERR_CAPACITY; }
   }
-  // tras_opt pass 1
-  int r = map_set_counter(s, st, CNT_FACTORS, 0, err); if (r) return r;
-  const MapParams P = map_params(s);
-  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
-  if (nn > 0) hipLaunchKernelGGL(k_extract_count, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, P, multi ? 1 : 0);
-  MAPCHK(hipGetLastError());
-  r = map_read_counters(s, st, err);
-  if (r) return r;
+  if (s.h_cnt[CNT_NODES] == 0) s.h_cnt[CNT_FACTORS] = 0;
   *n_factors = s.h_cnt[CNT_FACTORS];
   s.h_cnt[CNT_N] = multi ? 1 : 0;   // remembered for map_extract_factors
   return VBA_OK;
