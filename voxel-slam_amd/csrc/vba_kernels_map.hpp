@@ -500,10 +500,16 @@ __global__ void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int
     if (lc[9] != 0.0) cluster_transform_dev(lc, m.poses, pw0);
   } else {                                                  // VM:1510-1529
     for (int k = 0; k < 10; k++) add[k] = fix[k];
-    for (int i = 0; i < win_count; i++) {
+    double occ[VBA_MAX_WIN_DEV];                             // the N column of every slot first: one memory trip, not one per frame
+#pragma unroll
+    for (int i = 0; i < VBA_MAX_WIN_DEV; i++) occ[i] = (i < win_count) ? m.nlc[((size_t)9 * W + P.mp[i < win_count ? i : 0]) * cp + id] : 0.0;
+#pragma unroll
+    for (int i = 0; i < VBA_MAX_WIN_DEV; i++) {
+      if (i >= win_count || occ[i] == 0.0) continue;
       const int slot = P.mp[i];
-      for (int k = 0; k < 10; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
-      if (lc[9] != 0.0) {
+      for (int k = 0; k < 9; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
+      lc[9] = occ[i];
+      {
         double t[10];
         cluster_transform_dev(lc, m.poses + 12 * i, t);
         for (int k = 0; k < 10; k++) add[k] += t[k];
@@ -545,8 +551,15 @@ __global__ void k_margi_points(MapView m, MapParams P, int epoch, int has_var) {
   int *pn = m.pnode + (size_t)slot * mpz + p;
   const int node = *pn;
   *pn = -1;
-  if (node < 0 || m.ntake[node] != epoch) return;
-  const int q = atomicAdd(&m.cnt[CNT_FIX], 1);
+  const bool take = node >= 0 && m.ntake[node] == epoch;
+  // one atomic per wave on the pool counter (every taken point hitting the same address serialised the kernel: 41 us)
+  const unsigned long long mask = __ballot(take);
+  if (!take) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(&m.cnt[CNT_FIX], __popcll(mask));
+  base = __shfl(base, leader, 64);
+  const int q = base + __popcll(mask & ((1ull << lane) - 1ull));
   if (q >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; return; }
   const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
   const double *R = m.poses;
