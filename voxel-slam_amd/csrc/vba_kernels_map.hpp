@@ -427,54 +427,75 @@ __device__ __forceinline__ void cluster_transform_dev(const double *c /*10*/, co
 }
 
 // plane_update VM:1344-1388.  nplane layout: center(3) normal(3) radius(1) plane_var(36 row-major)
-__device__ void plane_update_dev(const MapView &m, int id, const double *add /*10*/, const double *ev /*3*/, const double *U /*9*/) {
+// Everything is unrolled onto registers (the caller is launched with 256-thread bounds): the first version indexed its local
+// arrays at run time and re-read cov_add from memory inside the triple loop — 564 B of scratch per lane, 243 loads.
+__device__ __forceinline__ void plane_update_dev(const MapView &m, int id, const double *add /*10*/, const double *ev /*3*/, const double *U /*9*/) {
   const size_t cp = (size_t)m.cap;
+  double cv[45];                                           // cov_add, upper triangle of the symmetric 9x9
+#pragma unroll
+  for (int k = 0; k < 45; k++) cv[k] = m.ncov[(size_t)k * cp + id];
   const double nv = 1.0 / add[9];
   const double c[3] = {add[6] * nv, add[7] * nv, add[8] * nv};
   const double u[3][3] = {{U[0], U[3], U[6]}, {U[1], U[4], U[7]}, {U[2], U[5], U[8]}};   // u[k] = column k
   double uc[3][9];
-  for (int r = 0; r < 3; r++) for (int k = 0; k < 9; k++) uc[r][k] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) uc[r][k] = 0.0;
+#pragma unroll
   for (int k = 1; k < 3; k++) {
     // ukl = u[k] u[0]^T ; fkl(0..5) from its symmetric part, fkl(6..8) = -(u[k].c u[0] + u[0].c u[k])
     double fkl[9];
-    const double *a = u[k], *b = u[0];
+    const double a[3] = {u[k][0], u[k][1], u[k][2]}, b[3] = {u[0][0], u[0][1], u[0][2]};
     fkl[0] = a[0] * b[0]; fkl[1] = a[1] * b[0] + a[0] * b[1]; fkl[2] = a[2] * b[0] + a[0] * b[2];
     fkl[3] = a[1] * b[1]; fkl[4] = a[1] * b[2] + a[2] * b[1]; fkl[5] = a[2] * b[2];
     const double ac = a[0] * c[0] + a[1] * c[1] + a[2] * c[2], bc = b[0] * c[0] + b[1] * c[1] + b[2] * c[2];
+#pragma unroll
     for (int j = 0; j < 3; j++) fkl[6 + j] = -(ac * b[j] + bc * a[j]);
     const double s = nv / (ev[0] - ev[k]);
-    for (int r = 0; r < 3; r++) for (int j = 0; j < 9; j++) uc[r][j] += s * a[r] * fkl[j];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) uc[r][j] += s * a[r] * fkl[j];
   }
   // Jc = u_c * cov_add (cov_add symmetric, upper triangle stored)
   double Jc[3][9];
+#pragma unroll
   for (int r = 0; r < 3; r++)
+#pragma unroll
     for (int j = 0; j < 9; j++) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 9; k++) {
         const int rr = k < j ? k : j, cc = k < j ? j : k;
-        s += uc[r][k] * m.ncov[(size_t)(rr * 9 - rr * (rr - 1) / 2 + (cc - rr)) * cp + id];
+        s += uc[r][k] * cv[rr * 9 - rr * (rr - 1) / 2 + (cc - rr)];
       }
       Jc[r][j] = s;
     }
   double *pl = m.nplane;
+#pragma unroll
   for (int j = 0; j < 3; j++) { pl[(size_t)j * cp + id] = c[j]; pl[(size_t)(3 + j) * cp + id] = u[0][j]; }
   pl[(size_t)6 * cp + id] = (double)(float)ev[2];   // float radius (VM:89, VM:1387)
   double pv[36];
+#pragma unroll
   for (int r = 0; r < 3; r++)
+#pragma unroll
     for (int cidx = 0; cidx < 3; cidx++) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 9; k++) s += Jc[r][k] * uc[cidx][k];
       pv[r * 6 + cidx] = s;                                // Jc * u_c^T
       const double jn = nv * Jc[r][6 + cidx];
       pv[r * 6 + 3 + cidx] = jn; pv[(3 + cidx) * 6 + r] = jn;   // Jc_N and its transpose
       const int rr = 6 + (r < cidx ? r : cidx), cc = 6 + (r < cidx ? cidx : r);
-      pv[(3 + r) * 6 + 3 + cidx] = nv * nv * m.ncov[(size_t)(rr * 9 - rr * (rr - 1) / 2 + (cc - rr)) * cp + id];
+      pv[(3 + r) * 6 + 3 + cidx] = nv * nv * cv[rr * 9 - rr * (rr - 1) / 2 + (cc - rr)];
     }
+#pragma unroll
   for (int k = 0; k < 36; k++) pl[(size_t)(7 + k) * cp + id] = pv[k];
 }
 
 // One thread per leaf: OctoTree::margi leaf branch VM:1468-1584 with mgsize = 1.
-__global__ void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int win_count, int epoch) {
+__global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int win_count, int epoch) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
