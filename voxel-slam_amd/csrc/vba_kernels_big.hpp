@@ -304,12 +304,12 @@ __global__ void k_gbab_rootid(GbaBigView g) {
 }
 // (LDS pre-aggregation per (node, frame) as k_gba_accum; the global (node, frame) table is probed once per occupied LDS entry)
 __global__ __launch_bounds__(256) void k_gbab_accum(GbaBigView g) {
-  __shared__ unsigned long long tkey[512];
-  __shared__ unsigned int tslot[512];
-  __shared__ double tacc[20][512];
+  __shared__ unsigned long long tkey[256];   // 256 points per workgroup -> at most 256 keys; 42 KB keeps three workgroups per CU
+  __shared__ unsigned int tslot[256];
+  __shared__ double tacc[20][256];
   const int tid = threadIdx.x;
-  for (int t = tid; t < 512; t += 256) tkey[t] = ~0ull;
-  for (int t = tid; t < 20 * 512; t += 256) (&tacc[0][0])[t] = 0.0;
+  tkey[tid] = ~0ull;
+  for (int t = tid; t < 20 * 256; t += 256) (&tacc[0][0])[t] = 0.0;
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + tid;
   const size_t n = (size_t)g.npts, cp = (size_t)g.cap, ct = (size_t)g.emask + 1;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_gbab_accum(GbaBigView g) {
     }
   }
   __syncthreads();
-  for (int e = tid; e < 512; e += 256) {
+  for (int e = tid; e < 256; e += 256) {
     const unsigned long long key = tkey[e];
     if (key == ~0ull) continue;
     unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & g.emask;
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void k_gbab_accum(GbaBigView g) {
     tslot[e] = h;
   }
   __syncthreads();
-  for (int t = tid; t < 20 * 512; t += 256) {
-    const int k = t >> 9, e = t & 511;
+  for (int t = tid; t < 20 * 256; t += 256) {
+    const int k = t >> 8, e = t & 255;
     const unsigned long long key = tkey[e];
     if (key == ~0ull) continue;
     const double v = tacc[k][e];

@@ -97,15 +97,15 @@ __global__ void k_gba_rootid(GbaView g) {
 // go to HBM as f64 atomics — at layer 0 every point of a window lands in ~10^2 root voxels and per-point global atomics
 // serialise on them.
 __device__ __forceinline__ unsigned int gba_lds_claim(unsigned long long *tkey, unsigned long long key) {
-  unsigned int e = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 55);
+  unsigned int e = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 56);
   while (true) {
     const unsigned long long old = atomicCAS(&tkey[e], ~0ull, key);
     if (old == ~0ull || old == key) break;
-    e = (e + 1) & 511;
+    e = (e + 1) & 255;
   }
   return e;
 }
-__device__ __forceinline__ void gba_lds_add(double (*tacc)[512], unsigned int e, double x, double y, double z, double wx, double wy, double wz) {
+__device__ __forceinline__ void gba_lds_add(double (*tacc)[256], unsigned int e, double x, double y, double z, double wx, double wy, double wz) {
   unsafeAtomicAdd(&tacc[0][e], wx * wx); unsafeAtomicAdd(&tacc[1][e], wx * wy); unsafeAtomicAdd(&tacc[2][e], wx * wz);
   unsafeAtomicAdd(&tacc[3][e], wy * wy); unsafeAtomicAdd(&tacc[4][e], wy * wz); unsafeAtomicAdd(&tacc[5][e], wz * wz);
   unsafeAtomicAdd(&tacc[6][e], wx); unsafeAtomicAdd(&tacc[7][e], wy); unsafeAtomicAdd(&tacc[8][e], wz); unsafeAtomicAdd(&tacc[9][e], 1.0);
@@ -115,11 +115,11 @@ __device__ __forceinline__ void gba_lds_add(double (*tacc)[512], unsigned int e,
 }
 
 __global__ __launch_bounds__(256) void k_gba_accum(GbaView g) {
-  __shared__ unsigned long long tkey[512];
-  __shared__ double tacc[20][512];
+  __shared__ unsigned long long tkey[256];   // 256 points per workgroup -> at most 256 keys; 42 KB keeps three workgroups per CU
+  __shared__ double tacc[20][256];
   const int tid = threadIdx.x;
-  for (int t = tid; t < 512; t += 256) tkey[t] = ~0ull;
-  for (int t = tid; t < 20 * 512; t += 256) (&tacc[0][0])[t] = 0.0;
+  tkey[tid] = ~0ull;
+  for (int t = tid; t < 20 * 256; t += 256) (&tacc[0][0])[t] = 0.0;
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + tid;
   const size_t n = (size_t)g.npts, cp = (size_t)g.cap;
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void k_gba_accum(GbaView g) {
     }
   }
   __syncthreads();
-  for (int t = tid; t < 20 * 512; t += 256) {
-    const int k = t >> 9, e = t & 511;
+  for (int t = tid; t < 20 * 256; t += 256) {
+    const int k = t >> 8, e = t & 255;
     const unsigned long long key = tkey[e];
     if (key == ~0ull) continue;
     const double v = tacc[k][e];

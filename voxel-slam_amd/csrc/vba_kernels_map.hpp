@@ -201,11 +201,11 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, 
 // world-frame pcr_add) are first summed per leaf in an LDS hash table of the workgroup (ds_add_f64) and only the table's
 // occupied entries go to HBM as f64 atomics: ~N_leaves x 20 instead of 256 x 20 global atomics per workgroup.
 __global__ __launch_bounds__(256) void k_ins_accum(MapView m, MapParams P, int slot, int n, int multi, int has_var) {
-  __shared__ int tkey[512];
-  __shared__ double tacc[20][512];
+  __shared__ int tkey[256];
+  __shared__ double tacc[20][256];   // 40 KB: three workgroups per CU (512 entries = 82 KB left one, i.e. one wave per SIMD)
   const int tid = threadIdx.x;
-  for (int t = tid; t < 512; t += 256) tkey[t] = -1;
-  for (int t = tid; t < 20 * 512; t += 256) (&tacc[0][0])[t] = 0.0;
+  tkey[tid] = -1;
+  for (int t = tid; t < 20 * 256; t += 256) (&tacc[0][0])[t] = 0.0;
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + tid;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(256) void k_ins_accum(MapView m, MapParams P, int s
       const double *R = m.poses;
       const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
       while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
-      unsigned int e = ((unsigned int)node * 2654435761u) >> 23;
+      unsigned int e = ((unsigned int)node * 2654435761u) >> 24;
       while (true) {
         const int old = atomicCAS(&tkey[e], -1, node);
         if (old == -1 || old == node) break;
-        e = (e + 1) & 511;
+        e = (e + 1) & 255;
       }
       // sw->pcrs_local[mord].push(pv.pnt) VM:1134 ; pcr_add.push(pw) VM:1136
       unsafeAtomicAdd(&tacc[0][e], bx * bx); unsafeAtomicAdd(&tacc[1][e], bx * by); unsafeAtomicAdd(&tacc[2][e], bx * bz);
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void k_ins_accum(MapView m, MapParams P, int s
     }
   }
   __syncthreads();
-  for (int t = tid; t < 20 * 512; t += 256) {
-    const int k = t >> 9, e = t & 511;
+  for (int t = tid; t < 20 * 256; t += 256) {
+    const int k = t >> 8, e = t & 255;
     const int node = tkey[e];
     if (node < 0) continue;
     const double v = tacc[k][e];
