@@ -372,17 +372,29 @@ __global__ void k_recut_fixpts(MapView m, MapParams P, int epoch, int child_laye
 }
 
 // tras_opt VM:1605-1638, pass 1: assign factor indices.
-__global__ void k_extract_count(MapView m, MapParams P, int multi) {
+// (one returning atomic per workgroup on the factor counter, as k_margi_points)
+__global__ __launch_bounds__(256) void k_extract_count(MapView m, MapParams P, int multi) {
+  __shared__ int wbase[4];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
-  if (id >= nn) return;
-  if (m.nstate[id] != 0) return;
-  if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;
-  if (!in_scope(m, P, id, multi)) return;
-  if (!(m.f_exist[id] && m.f_plane[id] && m.f_sw[id])) return;
+  bool take = id < nn && m.nstate[id] == 0;
+  if (take && multi && m.cnt[CNT_SLIDE] < P.thread_num) take = false;
+  if (take && !in_scope(m, P, id, multi)) take = false;
+  if (take && !(m.f_exist[id] && m.f_plane[id] && m.f_sw[id])) take = false;
   const size_t cp = (size_t)m.cap;
-  if (m.neval[id] / m.neval[cp + id] > 0.12) return;   // VM:1615
-  m.nopt[id] = atomicAdd(&m.cnt[CNT_FACTORS], 1);        // opt_state  VM:1626
+  if (take && m.neval[id] / m.neval[cp + id] > 0.12) take = false;   // VM:1615
+  const unsigned long long mask = __ballot(take);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int base = tot ? atomicAdd(&m.cnt[CNT_FACTORS], tot) : 0;
+    for (int w = 0; w < 4; w++) wbase[w] += base;
+  }
+  __syncthreads();
+  if (take) m.nopt[id] = wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull));   // opt_state  VM:1626
 }
 // pass 2: write the SoA factor store (push_voxel VM:139-147), frames in ring order pcrs[i] = pcrs_local[mp[i]] VM:1623-1624.
 // One thread per (node, row of the voxel's SoA record): rows 0..10W-1 = the body clusters, then fix (10), pcr (10), coe,
@@ -564,23 +576,35 @@ __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, Fact
 }
 
 // Frame-0 points of leaves that still collect fixed points -> pool, in world coordinates (VM:1549-1553); slot cleared.
-__global__ void k_margi_points(MapView m, MapParams P, int epoch, int has_var) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= m.max_pts) return;
+// The pool slots are claimed with ONE returning atomic per 1024-point workgroup: returning atomics on one address serialise
+// in L2 at ~10 ns each, and the hardware already merges a wave's lanes into one such operation — one per wave (4096 of them)
+// was the whole 41 us of this kernel.
+__global__ __launch_bounds__(1024) void k_margi_points(MapView m, MapParams P, int epoch, int has_var) {
+  __shared__ int wbase[16];
+  const int p = blockIdx.x * 1024 + threadIdx.x;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cf = (size_t)m.cap_fix;
   const int slot = P.mp[0];
-  int *pn = m.pnode + (size_t)slot * mpz + p;
-  const int node = *pn;
-  *pn = -1;
-  const bool take = node >= 0 && m.ntake[node] == epoch;
-  // one atomic per wave on the pool counter (every taken point hitting the same address serialised the kernel: 41 us)
+  int node = -1;
+  bool take = false;
+  if (p < m.max_pts) {
+    int *pn = m.pnode + (size_t)slot * mpz + p;
+    node = *pn;
+    *pn = -1;
+    take = node >= 0 && m.ntake[node] == epoch;
+  }
   const unsigned long long mask = __ballot(take);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int base = tot ? atomicAdd(&m.cnt[CNT_FIX], tot) : 0;
+    for (int w = 0; w < 16; w++) wbase[w] += base;
+  }
+  __syncthreads();
   if (!take) return;
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(&m.cnt[CNT_FIX], __popcll(mask));
-  base = __shfl(base, leader, 64);
-  const int q = base + __popcll(mask & ((1ull << lane) - 1ull));
+  const int q = wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull));
   if (q >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; return; }
   const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
   const double *R = m.poses;
@@ -1268,7 +1292,7 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   const dim3 gn((nn + 255) / 256), b(256);
   hipLaunchKernelGGL(k_margi_leaf, gn, b, 0, st, s.v, P, f, nfac, win_count, s.epoch);
   if (n_slide_before >= s.opt.thread_num) {
-    if (s.npts[slot0] > 0) hipLaunchKernelGGL(k_margi_points, dim3((s.v.max_pts + 255) / 256), b, 0, st, s.v, P, s.epoch, s.have_var ? 1 : 0);
+    if (s.npts[slot0] > 0) hipLaunchKernelGGL(k_margi_points, dim3((s.v.max_pts + 1023) / 1024), dim3(1024), 0, st, s.v, P, s.epoch, s.have_var ? 1 : 0);
     if (s.h_cnt[CNT_FIX] > 0) hipLaunchKernelGGL(k_margi_fixclear, dim3((s.h_cnt[CNT_FIX] + 255) / 256), b, 0, st, s.v, s.epoch);
     for (int L = s.opt.max_layer - 1; L >= 0; L--) hipLaunchKernelGGL(k_margi_up, gn, b, 0, st, s.v, P, L);
     hipLaunchKernelGGL(k_margi_roots, gn, b, 0, st, s.v, P, jour, s.epoch, n_slide_before);
