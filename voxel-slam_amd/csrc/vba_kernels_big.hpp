@@ -281,21 +281,7 @@ __global__ void k_gbab_keys(GbaBigView g, GbaParams P) {
   }
   g.pnode[p] = (int)h;
 }
-__global__ void k_gbab_roots(GbaBigView g, GbaParams P) {
-  const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > g.hmask) return;
-  const unsigned long long key = g.hkeys[s];
-  if (key == KEY_EMPTY) return;
-  const int id = atomicAdd(&g.cnt[GCNT_NODES], 1);
-  if (id >= g.cap) { atomicExch(&g.cnt[GCNT_OVERFLOW], 1); g.hvals[s] = -1; return; }
-  g.hvals[s] = id;
-  long long kx, ky, kz;
-  unpack_key(key, kx, ky, kz);
-  const size_t cp = (size_t)g.cap;
-  g.ncenter[id] = (0.5 + (double)kx) * P.voxel_size; g.ncenter[cp + id] = (0.5 + (double)ky) * P.voxel_size; g.ncenter[2 * cp + id] = (0.5 + (double)kz) * P.voxel_size;
-  g.nql[id] = (float)(P.voxel_size / 4.0);
-  g.nlayer[id] = 0; g.nchild[id] = -1; g.nfac[id] = -1;
-}
+__global__ __launch_bounds__(256) void k_gbab_roots(GbaBigView g, GbaParams P) { gba_roots_body(g, P, false); }
 __global__ void k_gbab_rootid(GbaBigView g) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= g.npts) return;
@@ -607,7 +593,7 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
     BIGCHK(hipMemsetAsync(g.nexi, 0, cp * 4, st));
     if (n > 0) {
       hipLaunchKernelGGL(k_gbab_keys, gp, bk, 0, st, g, P);
-      hipLaunchKernelGGL(k_gbab_roots, dim3((hcap + 255) / 256), bk, 0, st, g, P);
+      hipLaunchKernelGGL(k_gbab_roots, dim3((hcap + 4095) / 4096), bk, 0, st, g, P);
       hipLaunchKernelGGL(k_gbab_rootid, gp, bk, 0, st, g);
       for (int L = 0; L <= P.max_layer; L++) {
         // entries of the previous level are dead: a planar node keeps its own entries (it stopped descending), so the

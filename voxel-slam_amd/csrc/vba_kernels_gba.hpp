@@ -66,24 +66,56 @@ __global__ void k_gba_keys(GbaView g, GbaParams P) {
   g.pnode[p] = (int)h;     // slot for now; k_gba_rootid turns it into the node id
 }
 
-__global__ void k_gba_roots(GbaView g, GbaParams P) {
-  const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > g.hmask) return;
-  const unsigned long long key = g.hkeys[s];
-  if (key == KEY_EMPTY) return;
-  const int id = atomicAdd(&g.cnt[GCNT_NODES], 1);
-  if (id >= g.cap) { atomicExch(&g.cnt[GCNT_OVERFLOW], 1); g.hvals[s] = -1; return; }
-  atomicAdd(&g.cnt[GCNT_ROOTS], 1);
-  g.hvals[s] = id;
-  long long kx, ky, kz;
-  unpack_key(key, kx, ky, kz);
+// One root node per occupied hash slot.  A workgroup scans 4096 slots (16 per thread) and claims its node ids with ONE
+// returning atomic: per-slot claims serialise on the counter (~10 ns per wave-level operation, one per root: 48 us for a
+// few thousand roots in a 10^6-slot table).
+template <class View>
+__device__ __forceinline__ void gba_roots_body(View &g, const GbaParams &P, bool count_roots) {
+  __shared__ int wbase[4];
+  const unsigned int s0 = blockIdx.x * 4096u + threadIdx.x;
+  unsigned long long mk[16];
+  int wave_tot = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const unsigned int s = s0 + 256u * j;
+    const bool occ = s <= g.hmask && g.hkeys[s] != KEY_EMPTY;
+    mk[j] = __ballot(occ);
+    wave_tot += __popcll(mk[j]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = wave_tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int base = tot ? atomicAdd(&g.cnt[GCNT_NODES], tot) : 0;
+    if (tot && count_roots) atomicAdd(&g.cnt[GCNT_ROOTS], tot);
+    for (int w = 0; w < 4; w++) wbase[w] += base;
+  }
+  __syncthreads();
+  int running = wbase[wave];
   const size_t cp = (size_t)g.cap;
-  g.ncenter[id] = (0.5 + (double)kx) * P.voxel_size;
-  g.ncenter[cp + id] = (0.5 + (double)ky) * P.voxel_size;
-  g.ncenter[2 * cp + id] = (0.5 + (double)kz) * P.voxel_size;
-  g.nql[id] = (float)(P.voxel_size / 4.0);
-  g.nlayer[id] = 0; g.nchild[id] = -1; g.nfac[id] = -1;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const unsigned int s = s0 + 256u * j;
+    if ((mk[j] >> lane) & 1ull) {
+      const int id = running + __popcll(mk[j] & ((1ull << lane) - 1ull));
+      if (id >= g.cap) { atomicExch(&g.cnt[GCNT_OVERFLOW], 1); g.hvals[s] = -1; }
+      else {
+        g.hvals[s] = id;
+        long long kx, ky, kz;
+        unpack_key(g.hkeys[s], kx, ky, kz);
+        g.ncenter[id] = (0.5 + (double)kx) * P.voxel_size;
+        g.ncenter[cp + id] = (0.5 + (double)ky) * P.voxel_size;
+        g.ncenter[2 * cp + id] = (0.5 + (double)kz) * P.voxel_size;
+        g.nql[id] = (float)(P.voxel_size / 4.0);
+        g.nlayer[id] = 0; g.nchild[id] = -1; g.nfac[id] = -1;
+      }
+    }
+    running += __popcll(mk[j]);
+  }
 }
+__global__ __launch_bounds__(256) void k_gba_roots(GbaView g, GbaParams P) { gba_roots_body(g, P, true); }
 
 __global__ void k_gba_rootid(GbaView g) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,7 +331,7 @@ inline int gba_build(GbaStore &s, hipStream_t st, int W, const int *offsets, con
     GBACHK(hipMemsetAsync(s.v.nlc, 0, 10 * cp * W * 8, st));
     if (n > 0) {
       hipLaunchKernelGGL(k_gba_keys, gp, b, 0, st, s.v, P);
-      hipLaunchKernelGGL(k_gba_roots, dim3((s.cap_hash + 255) / 256), b, 0, st, s.v, P);
+      hipLaunchKernelGGL(k_gba_roots, dim3((s.cap_hash + 4095) / 4096), b, 0, st, s.v, P);
       hipLaunchKernelGGL(k_gba_rootid, gp, b, 0, st, s.v);
       for (int L = 0; L <= P.max_layer; L++) {
         hipLaunchKernelGGL(k_gba_accum, gp, b, 0, st, s.v);
