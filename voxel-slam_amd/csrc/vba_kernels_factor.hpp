@@ -528,8 +528,9 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   for (int t = tid; t < W * 12; t += C::NT) sp[t] = poses[t];
-  for (int t = tid; t < C::NK * (C::GS - C::NC); t += C::NT)       // padded columns stay zero for the whole kernel
-    G[(size_t)(t / (C::GS - C::NC)) * C::GS + C::NC + t % (C::GS - C::NC)] = 0.0;
+  constexpr int PADC = C::GS - C::NC;                               // padded columns (none at W = 8) stay zero for the whole kernel
+  if constexpr (PADC > 0)
+    for (int t = tid; t < C::NK * PADC; t += C::NT) G[(size_t)(t / PADC) * C::GS + C::NC + t % PADC] = 0.0;
 
   const int vl = tid % C::TV, fi = tid / C::TV;
   const bool slot_thread = fi < W;
