@@ -60,7 +60,7 @@ struct MapView {
   unsigned long long *hkeys; int *hvals; unsigned int hmask;
   // nodes
   int cap;
-  unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
+  unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
   signed char *nlayer; signed char *nstate;
   unsigned char *f_exist, *f_sw, *f_plane, *f_touched; int *f_slide;
   float *nql; double *ncenter; double *njour;
@@ -394,19 +394,20 @@ __global__ __launch_bounds__(256) void k_extract_count(MapView m, MapParams P, i
     for (int w = 0; w < 4; w++) wbase[w] += base;
   }
   __syncthreads();
-  if (take) m.nopt[id] = wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull));   // opt_state  VM:1626
+  if (take) {
+    const int a = wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+    m.nopt[id] = a;                                          // opt_state  VM:1626
+    m.nflist[a] = id;                                        // (a < number of nodes <= cap)
+  }
 }
 // pass 2: write the SoA factor store (push_voxel VM:139-147), frames in ring order pcrs[i] = pcrs_local[mp[i]] VM:1623-1624.
-// One thread per (node, row of the voxel's SoA record): rows 0..10W-1 = the body clusters, then fix (10), pcr (10), coe,
-// eigval (3), eigvec (9).  (One thread per node copying all 10W+33 scalars was latency-bound: 58 us for 26k factors.)
-__global__ void k_extract_write(MapView m, MapParams P, FactorView f, int multi) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
-  if (id >= nn) return;
-  if (m.nstate[id] != 0 || !in_scope(m, P, id, multi)) return;
-  if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;
-  const int a = m.nopt[id];
-  if (a < 0 || a >= f.vs) return;
+// One thread per (factor, row of the voxel's SoA record): rows 0..10W-1 = the body clusters, then fix (10), pcr (10), coe,
+// eigval (3), eigvec (9).  (One thread per node copying all 10W+33 scalars was latency-bound: 58 us for 26k factors; one
+// thread per (NODE, row) re-derived the node's eligibility 10W+33 times over every node: 36 us.)
+__global__ void k_extract_write(MapView m, MapParams P, FactorView f, int nfac) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;       // factor index; the leaf comes from the list k_extract_count wrote
+  if (a >= nfac || a >= f.vs) return;
+  const int id = m.nflist[a];
   const size_t cp = (size_t)m.cap, vs = (size_t)f.vs, W = (size_t)P.W;
   const int row = blockIdx.y, ncl = 10 * P.W;
   if (row < ncl) {
@@ -983,7 +984,7 @@ inline MapParams map_params(const MapStore &s) {
 inline std::vector<DevArr> node_arrays(MapView &v, int W) {
   return {
       {(void **)&v.nkey, 8, 1}, {(void **)&v.nroot, 4, 1}, {(void **)&v.nparent, 4, 1}, {(void **)&v.nchild, 4, 1}, {(void **)&v.npath, 4, 1},
-      {(void **)&v.nopt, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
+      {(void **)&v.nopt, 4, 1}, {(void **)&v.nflist, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
       {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
       {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
@@ -1266,8 +1267,8 @@ inline int map_extract_factors(MapStore &s, hipStream_t st, FactorView f, std::s
   *n_factors = 0;
   if (!s.allocated) return VBA_OK;
   const MapParams P = map_params(s);
-  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
-  if (nn > 0) hipLaunchKernelGGL(k_extract_write, dim3((nn + 255) / 256, 10 * s.opt.win_size + 33), dim3(256), 0, st, s.v, P, f, s.h_cnt[CNT_N]);
+  const int nfac = s.h_cnt[CNT_NODES] > 0 ? s.h_cnt[CNT_FACTORS] : 0;
+  if (nfac > 0) hipLaunchKernelGGL(k_extract_write, dim3((nfac + 255) / 256, 10 * s.opt.win_size + 33), dim3(256), 0, st, s.v, P, f, nfac);
   MAPCHK(hipGetLastError());
   *n_factors = s.h_cnt[CNT_FACTORS];
   return VBA_OK;
