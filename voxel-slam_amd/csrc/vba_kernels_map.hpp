@@ -129,7 +129,7 @@ __device__ __forceinline__ void init_node(const MapView &m, int id, unsigned lon
 
 // ------------------------------------------------------------------------------------------------ K1: insert
 // Phase 1: world transform, key, find-or-claim the hash slot of the root voxel.
-__global__ void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given, int stamp) {
+__global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given, int stamp) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
   int hslot = -1, root = -1;
@@ -168,11 +168,22 @@ __global__ void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_gi
   // Roots that existed before this call are marked here (isexist, sliding-map membership, per-scan touch count:
   // VM:1997-2001); roots created by this call are marked by k_ins_newroots.  Consecutive points of a scan mostly share
   // their root: only the first lane of each run issues the (contended) atomics.
+  // The two counters are bumped once per workgroup: thousands of single increments on one address serialise in L2.
+  __shared__ int won[2][4];
   const int prev_root = __shfl_up(root, 1, 64);
+  bool w_slide = false, w_touch = false;
   if (root >= 0 && ((threadIdx.x & 63) == 0 || prev_root != root)) {
     m.f_exist[root] = 1;
-    if (m.f_slide[root] == 0 && atomicExch(&m.f_slide[root], 1) == 0) atomicAdd(&m.cnt[CNT_SLIDE], 1);
-    if (m.nstamp[root] != stamp && atomicExch(&m.nstamp[root], stamp) != stamp) atomicAdd(&m.cnt[CNT_TOUCH], 1);
+    w_slide = m.f_slide[root] == 0 && atomicExch(&m.f_slide[root], 1) == 0;
+    w_touch = m.nstamp[root] != stamp && atomicExch(&m.nstamp[root], stamp) != stamp;
+  }
+  const unsigned long long ms = __ballot(w_slide), mt = __ballot(w_touch);
+  if ((threadIdx.x & 63) == 0) { won[0][threadIdx.x >> 6] = __popcll(ms); won[1][threadIdx.x >> 6] = __popcll(mt); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ns = won[0][0] + won[0][1] + won[0][2] + won[0][3], nt = won[1][0] + won[1][1] + won[1][2] + won[1][3];
+    if (ns) atomicAdd(&m.cnt[CNT_SLIDE], ns);
+    if (nt) atomicAdd(&m.cnt[CNT_TOUCH], nt);
   }
 }
 
