@@ -495,8 +495,15 @@ def main():
                 break
     except Exception:
         pass
-    roof = {"bound": "hbm", "kernel": "k_residual_w<10> (K4, evaluate_only_residual)", "achieved": res_gbs, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": res_gbs / HBM_PEAK_GBS, "traffic": traffic,
+    # `achieved` / `frac` are priced at the LONGER of the two durations (the live hipEvent figure and, when the committed
+    # rocprofv3 summary of this command is present, its average for the kernel): the event figure is the optimistic one.
+    use_prof = bool(rocprof_us) and args.workload == "hesai200k_w10" and world == 1 and rocprof_us > res_us
+    dur_us = rocprof_us if use_prof else res_us
+    ach_gbs = bytes_res / (dur_us * 1e-6) / 1e9 if dur_us > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": "k_residual_w<10> (K4, evaluate_only_residual)", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "duration_basis": "rocprofv3 average (profiles/r01_final_bench_kernel_stats.csv), longer than the live hipEvent figure" if use_prof else "live hipEvent span minus empty span",
+            "frac_at_hipevent_duration": res_gbs / HBM_PEAK_GBS,
             "avg_launch_us": res_us, "avg_span_us_raw": res_us_raw, "empty_span_us": null_us, "launches": n_res,
             "rocprofv3_avg_launch_us": rocprof_us if (args.workload == "hesai200k_w10" and world == 1) else None,
             "frac_at_rocprofv3_duration": (bytes_res / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (rocprof_us and args.workload == "hesai200k_w10" and world == 1) else None,
