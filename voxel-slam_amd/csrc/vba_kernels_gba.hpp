@@ -230,19 +230,25 @@ __global__ void k_gba_descend(GbaView g) {
   g.pnode[p] = base + 4 * bx + 2 * by + bz;
 }
 
+// One thread per (node, row of the factor record) — rows 0..10W-1 the body clusters, then fix (10, zero), pcr (10), coe,
+// eigval (3), eigvec (9); one thread per node copying all 10W+33 scalars in turn was latency-bound (32 us per window).
 __global__ void k_gba_extract(GbaView g, FactorView f) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = g.cnt[GCNT_NODES] < g.cap ? g.cnt[GCNT_NODES] : g.cap;
   if (id >= nn) return;
   const int a = g.nfac[id];
   if (a < 0 || a >= f.vs) return;
-  const size_t cp = (size_t)g.cap, vs = (size_t)f.vs, W = (size_t)g.W;
-  for (size_t i = 0; i < W; i++)
-    for (size_t k = 0; k < 10; k++) f.cl[(k * W + i) * vs + a] = g.nlc[(k * W + i) * cp + id];
-  for (size_t k = 0; k < 10; k++) { f.fix[k * vs + a] = 0.0; f.pcr[k * vs + a] = g.nadd[k * cp + id]; }
-  f.coe[a] = 1.0;
-  for (size_t k = 0; k < 3; k++) f.eigval[k * vs + a] = g.neval[k * cp + id];
-  for (size_t k = 0; k < 9; k++) f.eigvec[k * vs + a] = g.nevec[k * cp + id];
+  const size_t cp = (size_t)g.cap, vs = (size_t)f.vs;
+  const int row = blockIdx.y, ncl = 10 * g.W;
+  if (row < ncl) f.cl[(size_t)row * vs + a] = g.nlc[(size_t)row * cp + id];          // both are [k][W][.] with the same (k, i) order
+  else {
+    const int r = row - ncl;
+    if (r < 10) f.fix[(size_t)r * vs + a] = 0.0;
+    else if (r < 20) f.pcr[(size_t)(r - 10) * vs + a] = g.nadd[(size_t)(r - 10) * cp + id];
+    else if (r == 20) f.coe[a] = 1.0;
+    else if (r < 24) f.eigval[(size_t)(r - 21) * vs + a] = g.neval[(size_t)(r - 21) * cp + id];
+    else f.eigvec[(size_t)(r - 24) * vs + a] = g.nevec[(size_t)(r - 24) * cp + id];
+  }
 }
 
 // submap cloud VS:2957-2975: every keyframe's points in the frame of keyframe 0, stored as PCL floats

@@ -1201,7 +1201,7 @@ static int gba_build_into_store(vba_ctx *c, int wdsize, const int *offsets, cons
   if (st) return st;
   if (nf > 0) {
     const int nn = c->gba.h_cnt[GCNT_NODES] < c->gba.v.cap ? c->gba.h_cnt[GCNT_NODES] : c->gba.v.cap;
-    hipLaunchKernelGGL(k_gba_extract, dim3((nn + 255) / 256), dim3(256), 0, c->stream, c->gba.v, c->fv);
+    hipLaunchKernelGGL(k_gba_extract, dim3((nn + 255) / 256, 10 * wdsize + 33), dim3(256), 0, c->stream, c->gba.v, c->fv);
     HIPCHK(c, hipGetLastError());
   }
   span_end(c, "gba_build", sp);
