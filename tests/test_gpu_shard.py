@@ -77,3 +77,52 @@ def test_two_rank_sharded_lm_equals_single_rank(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     files = [p.name for p in tmp_path.iterdir()]
     assert "ok" in files, [(p.name, p.read_text()) for p in tmp_path.iterdir()]
+
+
+def _worker_hba(rank, world, port, out_dir):
+    import dataclasses
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import synth, capi
+    nk = 25                                                   # 4 windows of 10 every 5 keyframes -> 2 per rank
+    wk = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="hba_kf%d" % nk, win_size=nk, n_pts=6000)
+    sk = synth.make_scans(wk)
+    clouds = [p.astype(np.float32).astype(np.float64) for p in sk["points"]]
+    x0 = synth.poses_flat(sk["R0"], sk["p0"])
+    gba = (2.0, 0.1, [0.25] * 4)
+
+    def run(shard):
+        ctx = capi.Context(capi.options_from_workload(synth.CONFIGS["hesai200k_w10"], stream=torch.cuda.current_stream().cuda_stream))
+        if shard:
+            ctx.set_shard(rank, world)
+            ctx.set_torch_allreduce(torch, dist)
+        out = ctx.hba_global(clouds, x0, x0, *gba, 2)
+        ctx.close()
+        return out
+
+    e1, e2 = run(True)
+    if rank == 0:
+        f1, f2 = run(False)
+        ok = (e1.shape == f1.shape and e2.shape == f2.shape and len(e1) > 0 and len(e2) > 0
+              and np.array_equal(e1[:, :2], f1[:, :2]) and np.array_equal(e2[:, :2], f2[:, :2])
+              and np.abs(e1 - f1).max() < 1e-6 * max(1.0, np.abs(f1).max()) and np.abs(e2 - f2).max() < 1e-6 * max(1.0, np.abs(f2).max()))
+        open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write(
+            "edges %s %s vs %s %s | %g %g" % (e1.shape, e2.shape, f1.shape, f2.shape,
+                                             np.abs(e1 - f1).max() if e1.shape == f1.shape else -1, np.abs(e2 - f2).max() if e2.shape == f2.shape else -1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hba_window_replicas_equal_single_rank(tmp_path):
+    """Hierarchical global BA over two ranks: the bottom-layer windows are dealt to the ranks, clouds and edges
+    are gathered by sum all-reduce, the top-level window runs replicated; the edges equal the single-rank run."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_hba, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    files = [p.name for p in tmp_path.iterdir()]
+    assert "ok" in files, [(p.name, p.read_text()) for p in tmp_path.iterdir()]

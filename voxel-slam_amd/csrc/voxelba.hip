@@ -1422,7 +1422,15 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     const size_t nw = (size_t)(offsets[start + wdsize] - offsets[start]);
     n_sub_cap += nw; if (nw > n_win_max) n_win_max = nw;
   }
-  const size_t need = (n_all + n_sub_cap) * 3 + 64;
+  // More than one rank ("windows are independent problems => replicas across GPUs for the bottom layer"): window
+  // wi is optimised by rank wi % n_ranks with the collective switched off; every rank writes its windows' clouds at fixed
+  // offsets of a zeroed buffer and its edges into a zeroed record table, and ONE sum all-reduce of each is the gather.  The
+  // top-level window then runs replicated (identical inputs on every rank).
+  const bool replicas = c->collective() && c->n_ranks > 1;
+  int n_win = 0;
+  for (int start = 0; start + wdsize <= n_kf; start += mgsize) n_win++;
+  const size_t meta_per = 2 + (size_t)(wdsize * (wdsize - 1) / 2) * 20, n_meta = replicas ? meta_per * (size_t)n_win : 0;
+  const size_t need = (n_all + (replicas ? 2 : 1) * n_sub_cap) * 3 + n_meta + 64;
   if (need > c->hba_all_doubles) {
     if (c->d_hba_all) hipFree(c->d_hba_all);
     c->d_hba_all = nullptr; c->hba_all_doubles = 0;
@@ -1433,6 +1441,17 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   if (n_all > 0) HIPCHK(c, hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream));
   std::vector<int> ccnt(n_win_max > 0 ? n_win_max : 1);
   size_t sub_off = 0;
+  double *d_rep = d_sub + n_sub_cap * 3, *d_meta = d_rep + n_sub_cap * 3;      // replica mode only
+  std::vector<double> meta(n_meta, 0.0);
+  std::vector<size_t> cap_off;
+  const vba_allreduce_fn hook = c->allreduce;
+  if (replicas) {
+    HIPCHK(c, hipMemsetAsync(d_rep, 0, n_sub_cap * 3 * sizeof(double), c->stream));
+    c->allreduce = nullptr;                                                    // the windows' own LM loops must not enter a collective
+  }
+  struct Restore { vba_ctx *c; vba_allreduce_fn h; ~Restore() { c->allreduce = h; } } restore{c, hook};
+  int wi = -1;
+  size_t cap_run = 0;
   static const bool want_times = getenv("VBA_HBA_TIMES") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_g0 = want_times ? (hipStreamSynchronize(c->stream), now()) : 0.0;
@@ -1442,6 +1461,20 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     for (int i = 0; i <= wdsize; i++) off[i] = offsets[start + i] - offsets[start];
     std::vector<double> xs(poses_x0 + (size_t)start * 12, poses_x0 + (size_t)(start + wdsize) * 12);
     int ne = 0, nc = 0;
+    wi++;
+    if (replicas) {
+      cap_off.push_back(cap_run);
+      cap_run += (size_t)off[wdsize];
+      sub_first.push_back(start);
+      if (wi % c->n_ranks != c->rank) continue;
+      int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
+                                gba_eigen_value_array, 1, 2, edges.data(), &ne, d_rep + cap_off.back() * 3, ccnt.data(), &nc, nullptr, nullptr);
+      if (st) return st;
+      double *mrec = &meta[meta_per * (size_t)wi];
+      mrec[0] = nc; mrec[1] = ne;
+      std::memcpy(mrec + 2, edges.data(), (size_t)ne * 20 * sizeof(double));
+      continue;
+    }
     int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
                               gba_eigen_value_array, 1, 2, edges.data(), &ne, d_sub + sub_off * 3, ccnt.data(), &nc, nullptr, nullptr);
     if (st) return st;
@@ -1455,6 +1488,30 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     sub_first.push_back(start);
     sub_n.push_back(nc);
     sub_off += (size_t)nc;
+  }
+  if (replicas) {
+    // gather: sum of the zero-padded per-rank buffers
+    HIPCHK(c, hipMemcpyAsync(d_meta, meta.data(), n_meta * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (hook(c->allreduce_user, d_rep, n_sub_cap * 3, c->stream) || hook(c->allreduce_user, d_meta, n_meta, c->stream)) {
+      c->set_error("allreduce hook failed"); return VBA_ERR_HIP;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, n_meta * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int w = 0; w < n_win; w++) {
+      const double *mrec = &meta[meta_per * (size_t)w];
+      const int nc = (int)mrec[0], ne = (int)mrec[1], start = sub_first[w];
+      for (int e = 0; e < ne; e++) {
+        if (*n_edges1 >= cap1) return VBA_ERR_CAPACITY;
+        double *o = edges1_out + (size_t)(*n_edges1) * 20;
+        std::memcpy(o, mrec + 2 + (size_t)e * 20, 20 * sizeof(double));
+        o[0] += start; o[1] += start;
+        (*n_edges1)++;
+      }
+      if (nc > 0) HIPCHK(c, hipMemcpyAsync(d_sub + sub_off * 3, d_rep + cap_off[w] * 3, (size_t)nc * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      sub_n.push_back(nc);
+      sub_off += (size_t)nc;
+    }
   }
   const int ns = (int)sub_first.size();
   if (want_times) t_g1 = now();
