@@ -198,10 +198,19 @@ int vba_map_prune(vba_ctx *ctx, double jour, int dist);
 int vba_map_reset(vba_ctx *ctx);
 int vba_map_num_roots(vba_ctx *ctx);       /* surf_map.size() */
 int vba_map_num_slide_roots(vba_ctx *ctx); /* surf_map_slide.size() */
+/* Storage statistics of the device map (the reference new/deletes OctoTree nodes, VS:1787-1823; here pruned roots hand their
+ * node storage and hash slots back for reuse): out8 = [node high-water mark, free root nodes, free 8-node child blocks, root
+ * table capacity, root table slots in use (live roots + tombstones), live roots, sliding-map roots, fixed points]. */
+int vba_map_stats(vba_ctx *ctx, long long *out8);
 /* Leaf dump for inspection / parity tests: 39 doubles per leaf
  * [kx,ky,kz, layer, path, N_add, N_fix, is_plane, isexist, opt_state, eig_value(3), eig_vector(9), pcr_add(10),
  *  plane.center(3), plane.normal(3), plane.radius].  out == NULL returns the leaf count. */
 int vba_map_dump_leaves(vba_ctx *ctx, double *out, int max_leaves);
+/* The two covariance outputs of the map that the leaf dump does not carry: plane.plane_var (6x6; plane_update VM:1344-1388,
+ * consumed by OctoTree::match VM:1667-1672) and cov_add (9x9 symmetric; Bf_var VM:106-121 summed by push VM:1138-1140).
+ * 86 doubles per leaf: [kx,ky,kz, layer, path, plane_var(36 row-major), cov_add upper triangle (45, row by row)];
+ * same leaf set as vba_map_dump_leaves (order not defined).  out == NULL returns the leaf count. */
+int vba_map_dump_plane_var(vba_ctx *ctx, double *out, int max_leaves);
 
 /* ------------------------------------------------------------------------------------------------
  * Odometry scan-to-map ("next #1").
@@ -265,10 +274,17 @@ int vba_hba_global(vba_ctx *ctx, int n_kf, const int *offsets, const double *pnt
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU: voxels are sharded by root-voxel hash bucket; each rank evaluates its
  * shard and the packed [H | g | r] buffer is summed across ranks (the thread-sum of VM:571-581).
- * The reduction itself is supplied by the host program (torch.distributed/RCCL all_reduce on the
- * device buffer, stream-ordered on the context's stream).                                          */
+ * The reduction is RCCL inside the library (vba_rccl_init) or, for rehearsals without RCCL, a hook
+ * supplied by the host program; both are stream-ordered on the context's stream.                  */
 typedef int (*vba_allreduce_fn)(void *user, void *buf_dev, size_t n_doubles, void *stream);
 int vba_set_allreduce(vba_ctx *ctx, vba_allreduce_fn fn, void *user);
+/* RCCL inside the library: the context owns (vba_rccl_init) or adopts (vba_set_rccl_comm, an ncclComm_t) a communicator and issues
+ * ncclAllReduce(ncclDouble, ncclSum) / ncclAllGather on its own stream — no host code in the LM loop.  Rank 0 calls
+ * vba_rccl_get_unique_id (128 bytes, ncclUniqueId), the host program hands the bytes to every rank (any transport), every rank
+ * calls vba_rccl_init, which also applies vba_set_shard(rank, n_ranks).  The hook above stays for CPU-side rehearsals (gloo). */
+int vba_rccl_get_unique_id(void *out128);
+int vba_rccl_init(vba_ctx *ctx, const void *unique_id128, int rank, int n_ranks);
+int vba_set_rccl_comm(vba_ctx *ctx, void *nccl_comm);
 /* Which rank owns root voxel (kx,ky,kz) out of n_ranks (pure function, usable without a device). */
 int vba_shard_owner(int64_t kx, int64_t ky, int64_t kz, int n_ranks);
 int vba_set_shard(vba_ctx *ctx, int rank, int n_ranks);

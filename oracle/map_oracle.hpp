@@ -589,6 +589,18 @@ struct VoxelMapOracle {
     for (auto &kv : surf_map) dump_pv_rec(kv.second, out, cnt, max_leaves);
     return cnt;
   }
+  // cov_add (9x9, VM:106-121 summed at VM:1138-1140), upper triangle row by row (45), same traversal order as dump_leaves
+  void dump_ca_rec(OctoTree *n, double *&out, int &cnt, int max_leaves) {
+    if (n->octo_state == 0) {
+      if (cnt < max_leaves) { int k = 0; for (int r = 0; r < 9; r++) for (int c = r; c < 9; c++) out[k++] = n->cov_add(r, c); out += 45; }
+      cnt++;
+    } else for (int i = 0; i < 8; i++) if (n->leaves[i]) dump_ca_rec(n->leaves[i], out, cnt, max_leaves);
+  }
+  int dump_cov_add(double *out, int max_leaves) {
+    int cnt = 0;
+    for (auto &kv : surf_map) dump_ca_rec(kv.second, out, cnt, max_leaves);
+    return cnt;
+  }
 };
 
 }  // namespace vso

@@ -256,6 +256,7 @@ int vso_map_num_slide_roots(void *m) { return (int)((VoxelMapOracle *)m)->surf_m
 //   eig_value(3), eig_vector(9), pcr_add(10), center(3), normal(3), radius] = 10 + 3 + 9 + 10 + 7 = 39 doubles
 int vso_map_dump_leaves(void *m, double *out, int max_leaves) { return ((VoxelMapOracle *)m)->dump_leaves(out, max_leaves); }
 int vso_map_dump_plane_var(void *m, double *out, int max_leaves) { return ((VoxelMapOracle *)m)->dump_plane_var(out, max_leaves); }
+int vso_map_dump_cov_add(void *m, double *out, int max_leaves) { return ((VoxelMapOracle *)m)->dump_cov_add(out, max_leaves); }
 
 // lio_state_estimation (voxelslam.cpp:962-1098): state[25] + cov[225] in/out; pnt_body [n][3], var_body [n][9];
 // trace (optional) receives rows [match_num, |rot_add|, |tra_add|]; returns the bool result.

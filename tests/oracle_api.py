@@ -13,7 +13,8 @@ _ip = C.POINTER(C.c_int)
 
 
 def build():
-    src = [os.path.join(_ROOT, "oracle", f) for f in ("oracle_capi.cpp", "ba_oracle.hpp", "map_oracle.hpp", "smallmat.hpp")]
+    odir = os.path.join(_ROOT, "oracle")
+    src = [os.path.join(odir, f) for f in os.listdir(odir) if f.endswith((".cpp", ".hpp"))]
     if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"])
 
@@ -353,4 +354,11 @@ class VoxelMap:
         out = np.zeros((n, 36))
         if n:
             lib().vso_map_dump_plane_var(self.h, _p(out), C.c_int(n))
+        return out
+
+    def dump_cov_add(self):
+        n = lib().vso_map_dump_cov_add(self.h, None, C.c_int(0))
+        out = np.zeros((n, 45))
+        if n:
+            lib().vso_map_dump_cov_add(self.h, _p(out), C.c_int(n))
         return out

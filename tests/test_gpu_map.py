@@ -261,9 +261,65 @@ def test_var_init_and_pvec_update_parity(capi, oracle, synth):
     gd, od = ctx.dump_leaves(), om.dump_leaves()
     _compare_leaves(gd, od)
     g, o = _leaf_table(gd), _leaf_table(od)
+    # plane.plane_var (6x6, voxel_map.hpp:1356-1383) and cov_add (9x9, voxel_map.hpp:106-121 / 1138-1140), row a6 / a14
+    gp = {tuple(int(v) for v in r[:5]): r for r in ctx.dump_plane_var()}
+    opv, oca = om.dump_plane_var(), om.dump_cov_add()          # same traversal order as om.dump_leaves()
     npl = 0
-    for key, ro in o.items():
+    for row, ro in enumerate(od):
+        key = tuple(int(v) for v in ro[:5])
+        ca = oca[row]
+        assert np.abs(gp[key][41:] - ca).max() <= 1e-10 * max(np.abs(ca).max(), 1e-300), (key, "cov_add")
         if ro[7] and np.abs(ro[35:38]).max() > 0:
             assert abs(g[key][38] - ro[38]) < 1e-6 * max(1e-3, abs(ro[38]))
+            sgn = np.sign(np.dot(g[key][35:38], ro[35:38]))   # eigenvector sign is free: the cross blocks follow the normal's sign
+            G = gp[key][5:41].reshape(6, 6).copy(); O = opv[row].reshape(6, 6)
+            G[:3, 3:] *= sgn; G[3:, :3] *= sgn
+            assert np.abs(G - O).max() <= 1e-8 * np.abs(O).max(), (key, "plane_var", np.abs(G - O).max() / np.abs(O).max())
             npl += 1
     assert npl > 20
+
+
+def test_long_session_prune_reuses_hash_slots_and_nodes(capi, oracle, synth):
+    """A sensor that keeps moving (voxelslam.cpp:1800-1823 prunes roots that were last stamped >= dist ago): the root table must
+    not silt up with tombstones (insertion reuses them, the table is re-hashed at its size when they dominate) and the node
+    storage of pruned subtrees must be recycled; the map stays equal to the oracle's all the way."""
+    import dataclasses
+    wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], n_pts=4000)
+    s = synth.make_scans(wl)
+    W = wl.win_size
+    o = _opts(capi, wl)
+    o.max_points_per_scan = 64            # capacity hint -> the root table starts at 1024 slots
+    ctx = capi.Context(o)
+    om = _omap(oracle, wl)
+    of = oracle.Factor(W)
+    assert ctx.map_stats()["hash_capacity"] == 0 or True
+    pose0 = synth.poses_flat(s["R_gt"][:1], s["p_gt"][:1])[0]
+    win = 0
+    poses_win = []
+    high = []
+    created = 0
+    for k in range(40):
+        pose = pose0.copy(); pose[9] += 6.0 * k                       # the whole room moves with the sensor: all-new roots every scan
+        pts = s["points"][k % W]
+        ctx.cut_voxel(win, pts, pose, multi=True); om.cut_voxel(win, pts, pose, multi=True)
+        poses_win.append(pose); win += 1
+        ctx.recut(win, np.array(poses_win), multi=True); om.recut(win, np.array(poses_win), of, multi=True)
+        assert ctx.size() == of.size()
+        if win >= W:
+            ctx.margi(win, np.array(poses_win), jour=float(k)); om.margi(win, np.array(poses_win), of, jour=float(k))
+            ctx.slide(1); om.slide(1)
+            poses_win = poses_win[1:]; win -= 1
+        ctx.prune(float(k), dist=5); om.prune(float(k), dist=5)
+        assert ctx.num_roots() == om.num_roots() and ctx.num_slide_roots() == om.num_slide_roots()
+        st = ctx.map_stats()
+        high.append(st["nodes_high_water"])
+        assert st["hash_used"] <= st["hash_capacity"] // 2 + 4000     # never silts up: at most half full + one scan's worth
+        if k % 8 == 7:
+            _compare_leaves(ctx.dump_leaves(), om.dump_leaves())
+    st = ctx.map_stats()
+    # ~40 scans x ~1e3 roots were created and most of them pruned: far more than the 1024-slot table it started with
+    assert st["free_roots"] + st["free_blocks"] > 0
+    assert st["roots"] < 12000
+    # the node storage stopped growing once the pruning set in (steady state: what a scan creates, a prune hands back)
+    assert high[-1] <= high[20] + 64, (high[20], high[-1])
+    _compare_leaves(ctx.dump_leaves(), om.dump_leaves())

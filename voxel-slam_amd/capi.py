@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libvoxelba.so")
+LIB_PATH = os.environ.get("VBA_LIB") or os.path.join(_PKG, "libvoxelba.so")   # VBA_LIB: an alternative build (tools/ A/B runs)
 _dp = C.POINTER(C.c_double)
 
 OK = 0
@@ -27,8 +27,8 @@ EXPORTS = [
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
     "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_odom_lio_state_estimation_kdtree", "vba_odom_kdtree_reset", "vba_odom_kdtree_size", "vba_odom_kdtree_points", "vba_gba_build", "vba_hba_add_edge", "vba_hba_global", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
-    "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_dump_leaves", "vba_odom_lio_state_estimation",
-    "vba_set_allreduce", "vba_shard_owner", "vba_set_shard",
+    "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_stats", "vba_map_dump_leaves", "vba_map_dump_plane_var", "vba_odom_lio_state_estimation",
+    "vba_set_allreduce", "vba_rccl_get_unique_id", "vba_rccl_init", "vba_set_rccl_comm", "vba_shard_owner", "vba_set_shard",
     "vba_timing_enable", "vba_timing_select", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
     "vba_lm_begin", "vba_lm_refresh_eigen", "vba_lm_iterate", "vba_lm_end",
     "vba_io_save_pcd", "vba_io_load_pcd", "vba_io_save_pose", "vba_io_read_lidarstate",
@@ -363,11 +363,25 @@ class Context:
     def num_slide_roots(self):
         return self.lib.vba_map_num_slide_roots(self.h)
 
+    def map_stats(self):
+        out = (C.c_longlong * 8)()
+        self._chk(self.lib.vba_map_stats(self.h, out))
+        keys = ("nodes_high_water", "free_roots", "free_blocks", "hash_capacity", "hash_used", "roots", "slide_roots", "fixed_points")
+        return dict(zip(keys, [int(x) for x in out]))
+
     def dump_leaves(self):
         n = self.lib.vba_map_dump_leaves(self.h, None, C.c_int(0))
         out = np.zeros((max(n, 0), 39))
         if n > 0:
             self.lib.vba_map_dump_leaves(self.h, _p(out), C.c_int(n))
+        return out
+
+    def dump_plane_var(self):
+        """[kx,ky,kz,layer,path, plane_var(36), cov_add upper triangle (45)] per leaf."""
+        n = self.lib.vba_map_dump_plane_var(self.h, None, C.c_int(0))
+        out = np.zeros((max(n, 0), 86))
+        if n > 0:
+            self.lib.vba_map_dump_plane_var(self.h, _p(out), C.c_int(n))
         return out
 
     # ---- odometry
@@ -445,6 +459,18 @@ class Context:
                 return 1
         self._cb = ALLREDUCE_FN(tramp)
         self._chk(self.lib.vba_set_allreduce(self.h, self._cb, None))
+
+    def rccl_init(self, dist, rank, world):
+        """Native exchange step: rank 0 makes an ncclUniqueId, torch.distributed (any backend) carries its 128 bytes to the other
+        ranks, every rank builds the library's own RCCL communicator (vba_rccl_init also applies the voxel-bucket shard)."""
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            self._chk(self.lib.vba_rccl_get_unique_id(buf))
+        box = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        uid = C.create_string_buffer(box[0], 128)
+        self._chk(self.lib.vba_rccl_init(self.h, uid, C.c_int(rank), C.c_int(world)))
 
     def set_torch_allreduce(self, torch, dist):
         """torch.distributed SUM all-reduce (RCCL with backend "nccl", gloo in rehearsals) of the context's device buffers,

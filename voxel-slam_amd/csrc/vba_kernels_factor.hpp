@@ -6,6 +6,7 @@
 // doubles (512 B) per field — see DESIGN.md §3.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "vba_eig3.hpp"
 
 namespace vba {
 
@@ -92,8 +93,9 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 //   1. three Jacobi sweeps in f32 on the scaled matrix give eigenvectors V0 good to ~1e-7; V0 is re-orthonormalised in f64
 //      (Gram-Schmidt + cross product) and A' = V0^T A V0 is formed in f64 — an exact similarity with off-diagonals ~1e-7 |A|;
 //   2. the f64 sweeps start from (A', V0) and converge quadratically: two sweeps instead of five.
-__device__ __forceinline__ void eig3_sym_dev(double a00, double a01, double a02, double a11, double a12, double a22,
-                                             double &w0, double &w1, double &w2, double *V) {
+// (kept out of line: it is the rare fallback of eig3_sym_dev below, and inlining it would charge its registers to every caller)
+struct Eig3Out { double w0, w1, w2, V[9]; };      // returned by value (registers): a pointer to the caller's V would put V into scratch
+__device__ __noinline__ Eig3Out eig3_jacobi_dev(double a00, double a01, double a02, double a11, double a12, double a22) {
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
   const double scale = fmax(fmax(fmax(fabs(a00), fabs(a11)), fabs(a22)), fmax(fmax(fabs(a01), fabs(a02)), fabs(a12)));
   if (scale > 1e-290 && scale < 1e290 && (fabs(a01) + fabs(a02) + fabs(a12) != 0.0)) {
@@ -134,8 +136,22 @@ __device__ __forceinline__ void eig3_sym_dev(double a00, double a01, double a02,
   if (a11 < a00) { VBA_SWAP(a00, a11); VBA_SWAP(v00, v01); VBA_SWAP(v10, v11); VBA_SWAP(v20, v21); }
   if (a22 < a00) { VBA_SWAP(a00, a22); VBA_SWAP(v00, v02); VBA_SWAP(v10, v12); VBA_SWAP(v20, v22); }
   if (a22 < a11) { VBA_SWAP(a11, a22); VBA_SWAP(v01, v02); VBA_SWAP(v11, v12); VBA_SWAP(v21, v22); }
-  w0 = a00; w1 = a11; w2 = a22;
-  V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v10; V[4] = v11; V[5] = v12; V[6] = v20; V[7] = v21; V[8] = v22;
+  Eig3Out o;
+  o.w0 = a00; o.w1 = a11; o.w2 = a22;
+  o.V[0] = v00; o.V[1] = v01; o.V[2] = v02; o.V[3] = v10; o.V[4] = v11; o.V[5] = v12; o.V[6] = v20; o.V[7] = v21; o.V[8] = v22;
+  return o;
+}
+
+// The plane fit's eigen-solver: direct (vba_eig3.hpp: trigonometric seed + Newton for the isolated root, deflation, eigenvectors
+// from cross products and a 2x2 complement problem); matrices with a near-double eigenvalue pair, multiples of the identity and
+// non-finite input take the Jacobi sweeps above.
+__device__ __forceinline__ void eig3_sym_dev(double a00, double a01, double a02, double a11, double a12, double a22,
+                                             double &w0, double &w1, double &w2, double *V) {
+  if (eig3_direct(a00, a01, a02, a11, a12, a22, w0, w1, w2, V)) return;
+  const Eig3Out o = eig3_jacobi_dev(a00, a01, a02, a11, a12, a22);
+  w0 = o.w0; w1 = o.w1; w2 = o.w2;
+#pragma unroll
+  for (int k = 0; k < 9; k++) V[k] = o.V[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,164 +208,164 @@ __global__ void k_count_slots(FactorView f, int n, unsigned long long *out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: residual pass.  One thread per voxel; 64-thread workgroups so that V ~ 3e4 voxels still spread
-// over all 256 CUs.  Algorithmic traffic per voxel: read (W_occ+1)*80 + W*8 + 8 B, write 176 B.
+// K4: residual pass  <->  LidarFactor::evaluate_only_residual voxel_map.hpp:285-325 (+ PointCluster::transform tools.hpp:357-363).
+// Algorithmic traffic per voxel: read (W_occ + 1) * 80 + 8 B, write 176 B.
+//
+// Workgroup = TV voxels x W frames, one thread per (voxel, frame) SLOT; wave 0's first TV lanes double as the voxel threads.
+//   trip 1: every slot thread reads its N (the occupancy test), the voxel threads the fixed cluster + coe, W*12 threads the poses;
+//   trip 2: occupied slots read their 9 other scalars (empty slots cost 8 B, not 80 B);
+//   slot threads transform their cluster (~95 f64 operations) and park the 10 world-frame scalars in LDS;
+//   thread (voxel, k) adds scalar k of the W frames to the fixed cluster IN FRAME ORDER (the reference's order, VM:297-305: the
+//   sum does not depend on the launch) and writes pcr_adds (VM:319); the voxel threads solve the 3x3 eigen-problem
+//   (vba_eig3.hpp), write eig_values / eig_vectors back (VM:317-318) and reduce coe * lambda_0.
+// Why this shape (MI355X, bench window V = 18 391, S/V = 4.3): the first version gave a lane a whole voxel — the wave then issues the
+// transform of all W frames for every lane (exec-masked lanes still cost issue cycles): 950 f64 instructions x 4 cycles = 3.8k of
+// the pass's 22k cycles, and the Jacobi eigen-solve another 8.5k (in-kernel stamps, profiles/r01_k3_stamps.txt); one lane per slot
+// issues the transform once per wave, and ~3 waves per SIMD (instead of 0.3) overlap each other's memory trips.
 __device__ __forceinline__ double wave_sum(double x) {
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
   return x;
 }
 
-__global__ __launch_bounds__(64) void k_residual(FactorView f, const double *__restrict__ poses, int head, int end,
-                                                 double *__restrict__ partial, const int *__restrict__ gate) {
-  __shared__ double sp[VBA_MAX_WIN_DEV * 12];
-  if (gate && *gate == 0) return;   // device-side LM: the loop has stopped
-  const int W = f.W;
-  for (int t = threadIdx.x; t < W * 12; t += 64) sp[t] = poses[t];
-  __syncthreads();
-  const int v = head + blockIdx.x * 64 + threadIdx.x;
-  const size_t vs = (size_t)f.vs;
-  double r = 0.0;
-  if (v < end) {
-    double P00 = f.fix[0 * vs + v], P01 = f.fix[1 * vs + v], P02 = f.fix[2 * vs + v];
-    double P11 = f.fix[3 * vs + v], P12 = f.fix[4 * vs + v], P22 = f.fix[5 * vs + v];
-    double s0 = f.fix[6 * vs + v], s1 = f.fix[7 * vs + v], s2 = f.fix[8 * vs + v];
-    double N = f.fix[9 * vs + v];
-    for (int i = 0; i < W; i++) {
-      const double *c = f.cl + (size_t)i * vs + v;
-      const size_t fs = (size_t)W * vs;  // field stride
-      const double n = c[9 * fs];
-      if (n != 0.0) {
-        const double pxx = c[0], pxy = c[fs], pxz = c[2 * fs], pyy = c[3 * fs], pyz = c[4 * fs], pzz = c[5 * fs];
-        const double vx = c[6 * fs], vy = c[7 * fs], vz = c[8 * fs];
-        const double *R = sp + 12 * i;
-        const double tx = R[9], ty = R[10], tz = R[11];
-        // Rv = R v ; v' = Rv + n t                                  (tools.hpp:360)
-        const double rv0 = R[0] * vx + R[1] * vy + R[2] * vz;
-        const double rv1 = R[3] * vx + R[4] * vy + R[5] * vz;
-        const double rv2 = R[6] * vx + R[7] * vy + R[8] * vz;
-        // M = R P (3x3), then (R P R^T) lower triangle               (tools.hpp:362)
-        const double m00 = R[0] * pxx + R[1] * pxy + R[2] * pxz, m01 = R[0] * pxy + R[1] * pyy + R[2] * pyz, m02 = R[0] * pxz + R[1] * pyz + R[2] * pzz;
-        const double m10 = R[3] * pxx + R[4] * pxy + R[5] * pxz, m11 = R[3] * pxy + R[4] * pyy + R[5] * pyz, m12 = R[3] * pxz + R[4] * pyz + R[5] * pzz;
-        const double m20 = R[6] * pxx + R[7] * pxy + R[8] * pxz, m21 = R[6] * pxy + R[7] * pyy + R[8] * pyz, m22 = R[6] * pxz + R[7] * pyz + R[8] * pzz;
-        P00 += (m00 * R[0] + m01 * R[1] + m02 * R[2]) + 2.0 * rv0 * tx + n * tx * tx;
-        P01 += (m10 * R[0] + m11 * R[1] + m12 * R[2]) + (rv1 * tx + rv0 * ty) + n * ty * tx;
-        P02 += (m20 * R[0] + m21 * R[1] + m22 * R[2]) + (rv2 * tx + rv0 * tz) + n * tz * tx;
-        P11 += (m10 * R[3] + m11 * R[4] + m12 * R[5]) + 2.0 * rv1 * ty + n * ty * ty;
-        P12 += (m20 * R[3] + m21 * R[4] + m22 * R[5]) + (rv2 * ty + rv1 * tz) + n * tz * ty;
-        P22 += (m20 * R[6] + m21 * R[7] + m22 * R[8]) + 2.0 * rv2 * tz + n * tz * tz;
-        s0 += rv0 + n * tx; s1 += rv1 + n * ty; s2 += rv2 + n * tz;
-        N += n;
-      }
-    }
-    // cov = P/N - vBar vBar^T ; eigen                                     (voxel_map.hpp:308-313)
-    const double b0 = s0 / N, b1 = s1 / N, b2 = s2 / N;
-    double w0, w1, w2, V[9];
-    eig3_sym_dev(P00 / N - b0 * b0, P01 / N - b1 * b0, P02 / N - b2 * b0, P11 / N - b1 * b1, P12 / N - b2 * b1, P22 / N - b2 * b2,
-                 w0, w1, w2, V);
-    // write back eig_values / eig_vectors / pcr_adds                       (voxel_map.hpp:317-319)
-    f.eigval[0 * vs + v] = w0; f.eigval[1 * vs + v] = w1; f.eigval[2 * vs + v] = w2;
-#pragma unroll
-    for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + v] = V[k];
-    f.pcr[0 * vs + v] = P00; f.pcr[1 * vs + v] = P01; f.pcr[2 * vs + v] = P02; f.pcr[3 * vs + v] = P11; f.pcr[4 * vs + v] = P12;
-    f.pcr[5 * vs + v] = P22; f.pcr[6 * vs + v] = s0; f.pcr[7 * vs + v] = s1; f.pcr[8 * vs + v] = s2; f.pcr[9 * vs + v] = N;
-    r = f.coe[v] * w0;                                                    // voxel_map.hpp:323
+// Sum over the 64 lanes of a wave, result valid in LANE 63 only.  Data-parallel-primitive moves instead of ds_bpermute
+// (__shfl_xor goes through the LDS crossbar: ~100+ cycles per step, six dependent steps): quad swaps, row mirrors, then the
+// two row broadcasts of gfx9.  Fixed summation tree, so the result does not depend on the launch.
+__device__ __forceinline__ double dpp_mov_f64(double x, double old, const int ctrl, const int row_mask) {
+  const long long xi = __double_as_longlong(x), oi = __double_as_longlong(old);
+  int lo = (int)xi, hi = (int)(xi >> 32);
+  const int olo = (int)oi, ohi = (int)(oi >> 32);
+  switch (ctrl) {   // (the control word is an immediate operand)
+    case 0xB1: lo = __builtin_amdgcn_update_dpp(olo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(ohi, hi, 0xB1, 0xF, 0xF, false); break;
+    case 0x4E: lo = __builtin_amdgcn_update_dpp(olo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(ohi, hi, 0x4E, 0xF, 0xF, false); break;
+    case 0x141: lo = __builtin_amdgcn_update_dpp(olo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(ohi, hi, 0x141, 0xF, 0xF, false); break;
+    case 0x140: lo = __builtin_amdgcn_update_dpp(olo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(ohi, hi, 0x140, 0xF, 0xF, false); break;
+    case 0x142: lo = __builtin_amdgcn_update_dpp(olo, lo, 0x142, 0xA, 0xF, false); hi = __builtin_amdgcn_update_dpp(ohi, hi, 0x142, 0xA, 0xF, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(olo, lo, 0x143, 0xC, 0xF, false); hi = __builtin_amdgcn_update_dpp(ohi, hi, 0x143, 0xC, 0xF, false); break;
   }
-  r = wave_sum(r);
-  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+  (void)row_mask;
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double x) {
+  x += dpp_mov_f64(x, x, 0xB1, 0xF);      // quad_perm [1,0,3,2]
+  x += dpp_mov_f64(x, x, 0x4E, 0xF);      // quad_perm [2,3,0,1]
+  x += dpp_mov_f64(x, x, 0x141, 0xF);     // row_half_mirror
+  x += dpp_mov_f64(x, x, 0x140, 0xF);     // row_mirror: every lane of a 16-lane row holds the row's sum
+  x += dpp_mov_f64(x, 0.0, 0x142, 0xA);   // row_bcast15 into rows 1 and 3 (the others add 0)
+  x += dpp_mov_f64(x, 0.0, 0x143, 0xC);   // row_bcast31 into rows 2 and 3
+  return x;
 }
 
-// K4, latency-restructured (template on the window size so that every loop unrolls):
-//   round 1: the N column of all W slots + the fixed cluster + coe (independent loads, one round trip);
-//   round 2: the 9 remaining scalars of every OCCUPIED slot, all issued before the first use (lanes whose slot is empty
-//            are masked off, so empty slots still cost 8 B, not 80 B);
-//   then transforms, Jacobi eigen-solve, write-back.  The generic kernel above pays one dependent round trip per frame.
-// Poses are read through uniform (scalar) loads: the frame index is a compile-time constant after unrolling.
-__device__ long long *g_k4_stamps = nullptr;   // diagnostic only (VBA_K4_STAMPS): [wave][t0, loads done, transforms done, eig done, end]
+template <int W, int TV>
+struct ResCfg {
+  static constexpr int NT = ((TV * W + 63) / 64) * 64;      // threads per workgroup
+  static constexpr int NF = NT / TV;                        // thread rows (>= W): row fi owns frame fi and the scalars k = fi, fi + NF, ... < 10
+  static constexpr int KPT = (10 + NF - 1) / NF;            // scalars per thread in the frame sum
+  static_assert(TV <= 64 && (TV & (TV - 1)) == 0 && NT % TV == 0, "the voxel threads are the first TV lanes of wave 0");
+  static_assert(W * 12 <= NT, "one thread per pose scalar");
+};
 
-// NB = number of load batches: 1 keeps all 9W cluster scalars in flight (best when the pass is latency-bound, < 1 wave per
-// SIMD); 2 halves the register footprint (<= 128 VGPRs -> 4 waves per SIMD) for passes that fill the chip.
-template <int W, int NB>
-__global__ __launch_bounds__(64) void k_residual_w(FactorView f, const double *__restrict__ poses, int head, int end,
-                                                   double *__restrict__ partial, const int *__restrict__ gate) {
+template <int W, int TV, bool STAMPS>
+__global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f, const double *__restrict__ poses, int head, int end,
+                                                                  double *__restrict__ partial, const int *__restrict__ gate,
+                                                                  long long *__restrict__ stamps) {
+  using C = ResCfg<W, TV>;
+  __shared__ double T[10][W][TV];                               // world-frame cluster of every slot (zeros for empty slots)
+  __shared__ double S[10][TV];                                  // pcr_add of every voxel
+  __shared__ double sp[W * 12];
   // The gate (a flag the previous kernel wrote, ~2 us away on another XCD) and the first round of loads are requested
   // TOGETHER; the early exit is taken only after both are back, so a live pass pays one memory trip here, not two.
   const int gate_v = gate ? *gate : 1;
-  const int v = head + blockIdx.x * 64 + threadIdx.x;
+  const int tid = threadIdx.x, vl = tid % TV, fi = tid / TV;
+  const int v = head + blockIdx.x * TV + vl;
   const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
-  double r = 0.0;
+  const int vc = v < end ? v : end - 1;                         // clamped: trip 1 is issued unconditionally (end > head)
+  const int fic = fi < W ? fi : W - 1;
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-  long long *stp = g_k4_stamps;
-  if (stp) st0 = clock64();
-  const int vc = v < end ? v : (end > head ? end - 1 : head);      // clamped: the loads below are issued unconditionally
-  double nn[W];
+  if (STAMPS) st0 = clock64();
+  // ---- trip 1: N of the slot, this thread's scalars of the fixed cluster, coe (row 0), the poses
+  double n = f.cl[9 * fs + (size_t)fic * vs + vc];
+  const double pose_s = poses[tid < W * 12 ? tid : 0];
+  double acc[C::KPT];
 #pragma unroll
-  for (int i = 0; i < W; i++) nn[i] = f.cl[9 * fs + (size_t)i * vs + vc];
-  double P00 = f.fix[0 * vs + vc], P01 = f.fix[1 * vs + vc], P02 = f.fix[2 * vs + vc];
-  double P11 = f.fix[3 * vs + vc], P12 = f.fix[4 * vs + vc], P22 = f.fix[5 * vs + vc];
-  double s0 = f.fix[6 * vs + vc], s1 = f.fix[7 * vs + vc], s2 = f.fix[8 * vs + vc];
-  double N = f.fix[9 * vs + vc];
-  const double coe = f.coe[vc];
-#pragma unroll
-  for (int i = 0; i < W; i++) asm volatile("" : "+v"(nn[i]));       // keep the loads above the exit (they would be sunk below it)
-  asm volatile("" : "+v"(N));
+  for (int j = 0; j < C::KPT; j++) { const int k = fi + j * C::NF; acc[j] = f.fix[(size_t)(k < 10 ? k : 9) * vs + vc]; }
+  double coe = f.coe[vc];
+  asm volatile("" : "+v"(n), "+v"(coe), "+v"(acc[0]));          // keep the loads above the exit (they would be sunk below it)
   if (gate_v == 0) return;
-  if (v < end) {
-    constexpr int WB = (W + NB - 1) / NB;
+  if (tid < W * 12) sp[tid] = pose_s;
+  // ---- trip 2: the 9 other scalars of an occupied slot (empty slots cost 8 B, not 80 B)
+  const bool occ = fi < W && v < end && n != 0.0;
+  double c[9];
 #pragma unroll
-    for (int bt = 0; bt < NB; bt++) {
-    double c[WB][9];
+  for (int k = 0; k < 9; k++) c[k] = occ ? f.cl[(size_t)k * fs + (size_t)fi * vs + v] : 0.0;
+  __syncthreads();
+  if (occ) {
+    const double pxx = c[0], pxy = c[1], pxz = c[2], pyy = c[3], pyz = c[4], pzz = c[5];
+    const double vx = c[6], vy = c[7], vz = c[8];
+    const double *R = sp + 12 * fi;
+    const double R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5], R6 = R[6], R7 = R[7], R8 = R[8];
+    const double tx = R[9], ty = R[10], tz = R[11];
+    // Rv = R v ; v' = Rv + n t                                  (tools.hpp:360)
+    const double rv0 = R0 * vx + R1 * vy + R2 * vz;
+    const double rv1 = R3 * vx + R4 * vy + R5 * vz;
+    const double rv2 = R6 * vx + R7 * vy + R8 * vz;
+    // M = R P (3x3), then (R P R^T) lower triangle               (tools.hpp:362)
+    const double m00 = R0 * pxx + R1 * pxy + R2 * pxz, m01 = R0 * pxy + R1 * pyy + R2 * pyz, m02 = R0 * pxz + R1 * pyz + R2 * pzz;
+    const double m10 = R3 * pxx + R4 * pxy + R5 * pxz, m11 = R3 * pxy + R4 * pyy + R5 * pyz, m12 = R3 * pxz + R4 * pyz + R5 * pzz;
+    const double m20 = R6 * pxx + R7 * pxy + R8 * pxz, m21 = R6 * pxy + R7 * pyy + R8 * pyz, m22 = R6 * pxz + R7 * pyz + R8 * pzz;
+    T[0][fi][vl] = (m00 * R0 + m01 * R1 + m02 * R2) + 2.0 * rv0 * tx + n * tx * tx;
+    T[1][fi][vl] = (m10 * R0 + m11 * R1 + m12 * R2) + (rv1 * tx + rv0 * ty) + n * ty * tx;
+    T[2][fi][vl] = (m20 * R0 + m21 * R1 + m22 * R2) + (rv2 * tx + rv0 * tz) + n * tz * tx;
+    T[3][fi][vl] = (m10 * R3 + m11 * R4 + m12 * R5) + 2.0 * rv1 * ty + n * ty * ty;
+    T[4][fi][vl] = (m20 * R3 + m21 * R4 + m22 * R5) + (rv2 * ty + rv1 * tz) + n * tz * ty;
+    T[5][fi][vl] = (m20 * R6 + m21 * R7 + m22 * R8) + 2.0 * rv2 * tz + n * tz * tz;
+    T[6][fi][vl] = rv0 + n * tx; T[7][fi][vl] = rv1 + n * ty; T[8][fi][vl] = rv2 + n * tz;
+    T[9][fi][vl] = n;
+  } else if (fi < W) {
 #pragma unroll
-    for (int ii = 0; ii < WB; ii++) {
-      const int i = bt * WB + ii;
-      const bool occ = i < W && nn[i < W ? i : 0] != 0.0;
+    for (int k = 0; k < 10; k++) T[k][fi][vl] = 0.0;            // x + 0.0 = x: the frame sum below needs no occupancy test
+  }
+  __syncthreads();
+  // ---- frame sum: thread (vl, k) adds scalar k of the W frames to the fixed cluster IN FRAME ORDER (sig = sig_vecs[a]; sig += ...
+  //      VM:297-305), keeps it for the voxel thread and writes pcr_adds[a] (VM:319), 10 coalesced stores per workgroup row
 #pragma unroll
-      for (int k = 0; k < 9; k++) c[ii][k] = occ ? f.cl[(size_t)k * fs + (size_t)i * vs + v] : 0.0;
+  for (int j = 0; j < C::KPT; j++) {
+    const int k = fi + j * C::NF;
+    if (k < 10) {
+      double a = acc[j];
+#pragma unroll
+      for (int i = 0; i < W; i++) a += T[k][i][vl];
+      S[k][vl] = a;
+      if (v < end) f.pcr[(size_t)k * vs + v] = a;
     }
-#pragma unroll
-    for (int ii = 0; ii < WB; ii++) {
-      const int i = bt * WB + ii;
-      const double n = i < W ? nn[i < W ? i : 0] : 0.0;
-      if (n != 0.0) {
-        const double pxx = c[ii][0], pxy = c[ii][1], pxz = c[ii][2], pyy = c[ii][3], pyz = c[ii][4], pzz = c[ii][5];
-        const double vx = c[ii][6], vy = c[ii][7], vz = c[ii][8];
-        const double *R = poses + 12 * i;
-        const double tx = R[9], ty = R[10], tz = R[11];
-        const double rv0 = R[0] * vx + R[1] * vy + R[2] * vz;
-        const double rv1 = R[3] * vx + R[4] * vy + R[5] * vz;
-        const double rv2 = R[6] * vx + R[7] * vy + R[8] * vz;
-        const double m00 = R[0] * pxx + R[1] * pxy + R[2] * pxz, m01 = R[0] * pxy + R[1] * pyy + R[2] * pyz, m02 = R[0] * pxz + R[1] * pyz + R[2] * pzz;
-        const double m10 = R[3] * pxx + R[4] * pxy + R[5] * pxz, m11 = R[3] * pxy + R[4] * pyy + R[5] * pyz, m12 = R[3] * pxz + R[4] * pyz + R[5] * pzz;
-        const double m20 = R[6] * pxx + R[7] * pxy + R[8] * pxz, m21 = R[6] * pxy + R[7] * pyy + R[8] * pyz, m22 = R[6] * pxz + R[7] * pyz + R[8] * pzz;
-        P00 += (m00 * R[0] + m01 * R[1] + m02 * R[2]) + 2.0 * rv0 * tx + n * tx * tx;
-        P01 += (m10 * R[0] + m11 * R[1] + m12 * R[2]) + (rv1 * tx + rv0 * ty) + n * ty * tx;
-        P02 += (m20 * R[0] + m21 * R[1] + m22 * R[2]) + (rv2 * tx + rv0 * tz) + n * tz * tx;
-        P11 += (m10 * R[3] + m11 * R[4] + m12 * R[5]) + 2.0 * rv1 * ty + n * ty * ty;
-        P12 += (m20 * R[3] + m21 * R[4] + m22 * R[5]) + (rv2 * ty + rv1 * tz) + n * tz * ty;
-        P22 += (m20 * R[6] + m21 * R[7] + m22 * R[8]) + 2.0 * rv2 * tz + n * tz * tz;
-        s0 += rv0 + n * tx; s1 += rv1 + n * ty; s2 += rv2 + n * tz;
-        N += n;
-      }
-    }
-    }
-    if (stp) st1 = clock64();
-    const double b0 = s0 / N, b1 = s1 / N, b2 = s2 / N;
+  }
+  __syncthreads();
+  if (STAMPS) st1 = clock64();
+  double r = 0.0;
+  if (fi == 0 && v < end) {
+    // cov = P/N - vBar vBar^T ; eigen                                     (voxel_map.hpp:308-313)
+    const double Nv = S[9][vl];
+    double iN = __builtin_amdgcn_rcp(Nv);                              // 1 / N to full precision: v_rcp_f64 + two Newton steps
+    iN = iN * (2.0 - Nv * iN);
+    iN = iN * (2.0 - Nv * iN);
+    const double b0 = S[6][vl] * iN, b1 = S[7][vl] * iN, b2 = S[8][vl] * iN;
     double w0, w1, w2, V[9];
-    eig3_sym_dev(P00 / N - b0 * b0, P01 / N - b1 * b0, P02 / N - b2 * b0, P11 / N - b1 * b1, P12 / N - b2 * b1, P22 / N - b2 * b2,
-                 w0, w1, w2, V);
-    if (stp) st2 = clock64();
+    eig3_sym_dev(S[0][vl] * iN - b0 * b0, S[1][vl] * iN - b1 * b0, S[2][vl] * iN - b2 * b0, S[3][vl] * iN - b1 * b1, S[4][vl] * iN - b2 * b1,
+                 S[5][vl] * iN - b2 * b2, w0, w1, w2, V);
+    if (STAMPS) st2 = clock64();
+    // write back eig_values / eig_vectors                                  (voxel_map.hpp:317-318)
     f.eigval[0 * vs + v] = w0; f.eigval[1 * vs + v] = w1; f.eigval[2 * vs + v] = w2;
 #pragma unroll
     for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + v] = V[k];
-    f.pcr[0 * vs + v] = P00; f.pcr[1 * vs + v] = P01; f.pcr[2 * vs + v] = P02; f.pcr[3 * vs + v] = P11; f.pcr[4 * vs + v] = P12;
-    f.pcr[5 * vs + v] = P22; f.pcr[6 * vs + v] = s0; f.pcr[7 * vs + v] = s1; f.pcr[8 * vs + v] = s2; f.pcr[9 * vs + v] = N;
-    r = coe * w0;
+    r = coe * w0;                                                         // voxel_map.hpp:323
   }
-  r = wave_sum(r);
-  if (threadIdx.x == 0) partial[blockIdx.x] = r;
-  if (stp && threadIdx.x == 0 && blockIdx.x < 512) {
-    st3 = clock64();
-    long long *o = stp + (size_t)blockIdx.x * 4;
-    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+  if (tid < 64) {
+    r = wave_sum_to_lane63(r);
+    if (tid == 63) partial[blockIdx.x] = r;
+    if (STAMPS && tid == 63 && blockIdx.x < 2048) {
+      st3 = clock64();
+      long long *o = stamps + (size_t)blockIdx.x * 4;
+      o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
   }
 }
 

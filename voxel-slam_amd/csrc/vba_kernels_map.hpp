@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <functional>
 #include "../../include/voxelba.h"
 #include "vba_kernels_factor.hpp"
 
@@ -45,7 +46,12 @@ __host__ __device__ inline long long key_axis(double pw, double voxel_size) {
   return (long long)loc;
 }
 
-enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_SNAP, CNT_N };
+// CNT_USED = hash slots that are not EMPTY (live roots + tombstones); CNT_FREE_ROOTS / CNT_FREE_BLOCKS = depth of the two
+// free-node stacks that map pruning fills and node creation drains
+enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_SNAP,
+       CNT_USED, CNT_FREE_ROOTS, CNT_FREE_BLOCKS,
+       CNT_SLIDE_G, CNT_TOUCH_G,   // the two counts the reference's 'fewer voxels than threads' quirks test, summed over the ranks when the map is sharded
+       CNT_N };
 
 struct MapParams {
   int W, max_layer, max_points, thread_num;
@@ -61,6 +67,7 @@ struct MapView {
   // nodes
   int cap;
   unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
+  int *nfree_root, *nfree_blk;   // stacks of recycled node ids: single root nodes / bases of 8-node child blocks (map_prune)
   signed char *nlayer; signed char *nstate;
   unsigned char *f_exist, *f_sw, *f_plane, *f_touched; int *f_slide;
   float *nql; double *ncenter; double *njour;
@@ -127,6 +134,25 @@ __device__ __forceinline__ void init_node(const MapView &m, int id, unsigned lon
   m.nql[id] = ql; m.ncenter[id] = cx; m.ncenter[cp + id] = cy; m.ncenter[2 * cp + id] = cz; m.njour[id] = 0.0;
 }
 
+// Node storage is recycled through two stacks that map pruning fills (k_prune_*): single nodes (roots) and 8-node child blocks.
+// Only pops run concurrently (node creation), pushes only inside the prune kernels, so a counter decrement is a safe pop; a pop
+// that finds the stack empty gives its decrement back and takes fresh storage from the end of the node arrays.
+__device__ __forceinline__ int alloc_nodes(const MapView &m, int which_cnt, const int *stack, int count) {
+  if (m.cnt[which_cnt] > 0) {
+    const int k = atomicSub(&m.cnt[which_cnt], 1) - 1;
+    if (k >= 0) return stack[k];
+    atomicAdd(&m.cnt[which_cnt], 1);
+  }
+  return atomicAdd(&m.cnt[CNT_NODES], count);
+}
+
+// The reference tests "#voxels < thread_num" on the whole map (VM:2044, VS:1616, VS:1693).  A sharded rank holds only its bucket
+// range, so those tests read the counts summed over the ranks (refreshed by a tiny all-reduce before the kernels that test them).
+__device__ __forceinline__ int slide_count(const MapView &m, const MapParams &P) { return P.n_ranks > 1 ? m.cnt[CNT_SLIDE_G] : m.cnt[CNT_SLIDE]; }
+__device__ __forceinline__ int touch_count(const MapView &m, const MapParams &P) { return P.n_ranks > 1 ? m.cnt[CNT_TOUCH_G] : m.cnt[CNT_TOUCH]; }
+__global__ void k_cnt_to_f64(const int *cnt, int which, double *out) { out[0] = (double)cnt[which]; }
+__global__ void k_f64_to_cnt(const double *in, int *cnt, int which) { cnt[which] = (int)(in[0] + 0.5); }
+
 // ------------------------------------------------------------------------------------------------ K1: insert
 // Phase 1: world transform, key, find-or-claim the hash slot of the root voxel.
 __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given, int stamp) {
@@ -148,20 +174,42 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
     if (ok && P.n_ranks > 1 && (int)((shard_bucket(kx, ky, kz) * (uint64_t)P.n_ranks) >> 16) != P.rank) ok = false;  // not this rank's bucket range
     if (ok) {
       const unsigned long long key = pack_key(kx, ky, kz);
-      unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & m.hmask;
-      for (unsigned int probe = 0; probe <= m.hmask; probe++) {
-        unsigned long long cur = m.hkeys[h];
-        if (cur == key) break;
-        if (cur == KEY_EMPTY) {
-          const unsigned long long prev = atomicCAS(&m.hkeys[h], KEY_EMPTY, key);
-          if (prev == KEY_EMPTY) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = (int)h; break; }
-          if (prev == key) break;
+      const unsigned int h0 = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 32) & m.hmask;
+      // Find the key, else claim a slot for it: the FIRST tombstone of the probe sequence (slots of pruned roots are reused, so
+      // the table cannot silt up with them over a long session) or, when the sequence holds none, its first EMPTY slot.
+      // A claim lost to another key restarts the scan; the scan is bounded by the table size, the restarts by a small count.
+      unsigned int h = h0;
+      bool found = false;
+      for (int attempt = 0; attempt < 64 && !found; attempt++) {
+        h = h0;
+        int tomb = -1;
+        bool restart = false;
+        for (unsigned int probe = 0; probe <= m.hmask; probe++) {
+          const unsigned long long cur = m.hkeys[h];
+          if (cur == key) { found = true; break; }
+          if (cur == KEY_TOMB && tomb < 0) tomb = (int)h;
+          if (cur == KEY_EMPTY) {
+            if (tomb >= 0) {
+              const unsigned long long prev = atomicCAS(&m.hkeys[tomb], KEY_TOMB, key);
+              if (prev == KEY_TOMB) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = tomb | (int)0x40000000; h = (unsigned int)tomb; found = true; break; }
+              if (prev == key) { h = (unsigned int)tomb; found = true; break; }
+              restart = true; break;                        // another key took the tombstone: scan again
+            }
+            const unsigned long long prev = atomicCAS(&m.hkeys[h], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = (int)h; found = true; break; }
+            if (prev == key) { found = true; break; }
+            // another key took this slot: it is an ordinary occupied slot now, keep probing
+          }
+          h = (h + 1) & m.hmask;
         }
-        h = (h + 1) & m.hmask;
+        if (!found && !restart) break;                      // a full sweep without the key, a tombstone or an EMPTY slot
       }
-      hslot = (int)h;
-      // hvals is only written by the next kernel, so a valid id here means "this root existed before the call"
-      if (!world_given) root = m.hvals[h];
+      if (!found) m.cnt[CNT_OVERFLOW] = 4;                   // table full: never fall through to an unrelated slot
+      else {
+        hslot = (int)h;
+        // hvals is only written by the next kernel, so a valid id here means "this root existed before the call"
+        if (!world_given) root = m.hvals[h];
+      }
     }
     m.phash[p] = hslot;
   }
@@ -191,8 +239,10 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
 __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, int stamp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.cnt[CNT_NEWSLOTS]) return;
-  const int h = m.newslots[i];
-  const int id = atomicAdd(&m.cnt[CNT_NODES], 1);
+  const int hs = m.newslots[i];
+  const int h = hs & 0x3FFFFFFF;
+  if (!(hs & 0x40000000)) atomicAdd(&m.cnt[CNT_USED], 1);     // a formerly EMPTY slot (a reused tombstone was counted when first claimed)
+  const int id = alloc_nodes(m, CNT_FREE_ROOTS, m.nfree_root, 1);
   if (id >= m.cap) { m.cnt[CNT_OVERFLOW] = 1; return; }
   long long kx, ky, kz;
   const unsigned long long key = m.hkeys[h];
@@ -220,7 +270,7 @@ __global__ __launch_bounds__(256) void k_ins_accum(MapView m, MapParams P, int s
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + tid;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
-  const bool dropped = multi && m.cnt[CNT_TOUCH] < P.thread_num;   // VM:2044-2045: the scan is dropped
+  const bool dropped = multi && touch_count(m, P) < P.thread_num;   // VM:2044-2045: the scan is dropped
   if (p < n) {
     int *pn = m.pnode + (size_t)slot * mpz + p;
     *pn = -1;
@@ -301,7 +351,7 @@ __global__ void k_recut_leaf(MapView m, MapParams P, int L, int multi, int epoch
   const int nn = m.cnt[CNT_SNAP] < m.cap ? m.cnt[CNT_SNAP] : m.cap;
   if (id >= nn) return;
   if (m.nlayer[id] != L || m.nstate[id] != 0) return;
-  if (multi && m.cnt[CNT_SLIDE] < P.thread_num) return;   // VS:1693-1694
+  if (multi && slide_count(m, P) < P.thread_num) return;   // VS:1693-1694
   if (!in_scope(m, P, id, multi)) return;
   const size_t cp = (size_t)m.cap;
   m.nopt[id] = -1;
@@ -319,7 +369,7 @@ __global__ void k_recut_leaf(MapView m, MapParams P, int L, int multi, int epoch
   m.f_plane[id] = plane ? 1 : 0;
   if (plane || L >= P.max_layer) return;
   // subdivide: children are created as a block of 8 (untouched octants stay empty leaves, which every traversal skips)
-  const int base = atomicAdd(&m.cnt[CNT_NODES], 8);
+  const int base = alloc_nodes(m, CNT_FREE_BLOCKS, m.nfree_blk, 8);
   if (base + 8 > m.cap) { m.cnt[CNT_OVERFLOW] = 1; return; }
   const double cx = m.ncenter[id], cy = m.ncenter[cp + id], cz = m.ncenter[2 * cp + id];
   const float ql = m.nql[id];
@@ -389,7 +439,7 @@ __global__ __launch_bounds__(256) void k_extract_count(MapView m, MapParams P, i
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   bool take = id < nn && m.nstate[id] == 0;
-  if (take && multi && m.cnt[CNT_SLIDE] < P.thread_num) take = false;
+  if (take && multi && slide_count(m, P) < P.thread_num) take = false;
   if (take && !in_scope(m, P, id, multi)) take = false;
   if (take && !(m.f_exist[id] && m.f_plane[id] && m.f_sw[id])) take = false;
   const size_t cp = (size_t)m.cap;
@@ -523,8 +573,8 @@ __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, Fact
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
-  if (m.nstate[id] != 0) return;
-  if (m.cnt[CNT_SLIDE] < P.thread_num) return;              // VS:1616-1617
+  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return;        // internal node, or freed storage
+  if (slide_count(m, P) < P.thread_num) return;              // VS:1616-1617
   if (m.f_slide[m.nroot[id]] == 0) return;
   if (!m.f_exist[id] || !m.f_sw[id]) return;                // VM:1471-1472
   const size_t cp = (size_t)m.cap, W = (size_t)P.W, vs = (size_t)f.vs;
@@ -637,7 +687,7 @@ __global__ void k_margi_up(MapView m, MapParams P, int L) {
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
   if (m.nlayer[id] != L || m.nstate[id] != 1) return;
-  if (m.cnt[CNT_SLIDE] < P.thread_num || m.f_slide[m.nroot[id]] == 0) return;
+  if (slide_count(m, P) < P.thread_num || m.f_slide[m.nroot[id]] == 0) return;
   unsigned char e = 0;
   const int base = m.nchild[id];
   for (int o = 0; o < 8; o++) e |= m.f_exist[base + o];
@@ -658,7 +708,7 @@ __global__ void k_margi_clear_nodes(MapView m, MapParams P, int epoch) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
-  if (m.ndead[m.nroot[id]] != epoch || !m.f_sw[id]) return;
+  if (m.nlayer[id] < 0 || m.ndead[m.nroot[id]] != epoch || !m.f_sw[id]) return;
   const size_t cp = (size_t)m.cap;
   for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
   m.f_sw[id] = 0;
@@ -690,18 +740,49 @@ __global__ void k_prune_roots(MapView m, double jour, int dist, int epoch) {
   atomicSub(&m.cnt[CNT_ROOTS], 1);
   if (m.f_slide[root]) { m.f_slide[root] = 0; atomicSub(&m.cnt[CNT_SLIDE], 1); }
 }
+// Freed nodes go onto the free stacks: an internal node hands back its child block, a root itself.  (Every node of a dead
+// subtree is visited: children are freed by their parent, so a child never pushes itself.)
 __global__ void k_prune_nodes(MapView m, int epoch) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
   if (m.nlayer[id] < 0 || m.ndead[m.nroot[id]] != epoch) return;
-  if (m.nroot[id] != id) m.nlayer[id] = -1;     // children first become unreachable ...
+  if (m.nstate[id] == 1) { const int k = atomicAdd(&m.cnt[CNT_FREE_BLOCKS], 1); m.nfree_blk[k] = m.nchild[id]; }
+  if (m.nroot[id] == id) { const int k = atomicAdd(&m.cnt[CNT_FREE_ROOTS], 1); m.nfree_root[k] = id; }
+  else m.nlayer[id] = -1;                       // children first become unreachable ...
 }
 __global__ void k_prune_finish(MapView m, int epoch) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   if (id >= nn) return;
-  if (m.nroot[id] == id && m.ndead[id] == epoch) m.nlayer[id] = -1;   // ... then the roots themselves
+  if (m.nroot[id] == id && m.ndead[id] == epoch && m.nlayer[id] >= 0) m.nlayer[id] = -1;   // ... then the roots themselves
+}
+// The accumulators of a freed node are zeroed so that its next owner starts like fresh storage (which is zero-filled at
+// allocation): one thread per (node, row) of [pcr_add 10 | pcr_fix 10 | cov_add 45 | eig 12 | plane 43 | local clusters 10 W].
+__global__ void k_prune_zero(MapView m, int W, int epoch) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nlayer[id] >= 0) return;
+  if (m.ndead[m.nroot[id]] != epoch) return;    // freed by an earlier prune (zeroed then)
+  const size_t cp = (size_t)m.cap;
+  int r = blockIdx.y;
+  if (r == 0) {   // a stale flag must not make a later pass take the freed node for a live leaf (its nroot may be re-owned by then)
+    m.f_exist[id] = 0; m.f_sw[id] = 0; m.f_plane[id] = 0; m.f_touched[id] = 0; m.nstate[id] = 0; m.nopt[id] = -1; m.nchild[id] = -1;
+  }
+  if (r < 10) { m.nadd[(size_t)r * cp + id] = 0.0; return; }
+  r -= 10;
+  if (r < 10) { m.nfix[(size_t)r * cp + id] = 0.0; return; }
+  r -= 10;
+  if (r < 45) { m.ncov[(size_t)r * cp + id] = 0.0; return; }
+  r -= 45;
+  if (r < 3) { m.neval[(size_t)r * cp + id] = 0.0; return; }
+  r -= 3;
+  if (r < 9) { m.nevec[(size_t)r * cp + id] = 0.0; return; }
+  r -= 9;
+  if (r < 43) { m.nplane[(size_t)r * cp + id] = 0.0; return; }
+  r -= 43;
+  if (r < 10 * W) m.nlc[(size_t)r * cp + id] = 0.0;
 }
 __global__ void k_prune_fix(MapView m) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -842,6 +923,25 @@ __global__ void k_dump_leaves(MapView m, double *out, int max_leaves) {
   for (int k = 0; k < 7; k++) o[32 + k] = m.nplane[(size_t)k * cp + id];
 }
 
+// plane.plane_var (6x6, VM:1356-1383) and cov_add (9x9 symmetric, upper triangle; VM:106-121, 1138-1140) of every leaf, keyed like
+// k_dump_leaves: [kx,ky,kz, layer, path, plane_var(36 row-major), cov_add upper triangle (45)] = 86 doubles.
+__global__ void k_dump_plane_var(MapView m, double *out, int max_leaves) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if (id >= nn) return;
+  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return;
+  if (m.nlayer[id] > 0 && !m.f_touched[id]) return;
+  const int i = atomicAdd(&m.cnt[CNT_LEAVES], 1);
+  if (i >= max_leaves) return;
+  const size_t cp = (size_t)m.cap;
+  double *o = out + (size_t)i * 86;
+  long long kx, ky, kz;
+  unpack_key(m.nkey[id], kx, ky, kz);
+  o[0] = (double)kx; o[1] = (double)ky; o[2] = (double)kz; o[3] = m.nlayer[id]; o[4] = m.npath[id];
+  for (int k = 0; k < 36; k++) o[5 + k] = m.nplane[(size_t)(7 + k) * cp + id];
+  for (int k = 0; k < 45; k++) o[41 + k] = m.ncov[(size_t)k * cp + id];
+}
+
 __global__ void k_fill_u64(unsigned long long *p, unsigned long long v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -948,6 +1048,8 @@ __global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
 }
 
 // ================================================================================================ host side
+__global__ void k_set_counter(int *cnt, int which, int val) { cnt[which] = val; }
+__global__ void k_copy_counter(int *cnt, int from, int to) { cnt[to] = cnt[from]; }
 struct DevArr {  // a [rows][cap] device array that can grow its cap keeping [rows][used]
   void **slot; size_t elem, rows;
 };
@@ -965,10 +1067,13 @@ struct MapStore {
   int *h_cnt = nullptr;    // pinned
   // Inserts are enqueued without reading the counters back: the host keeps pessimistic upper bounds (every point may
   // create a root) and re-reads the true counters only when a bound would exceed a capacity.
-  long long ub_nodes = 0, ub_roots = 0;
+  long long ub_nodes = 0, ub_roots = 0, ub_used = 0;   // ub_used: hash slots that are not EMPTY (live roots + tombstones)
   bool cnt_stale = false;
   double *h_pose_ring = nullptr; hipEvent_t pose_ev[8] = {nullptr}; int pose_next = 0;
   void *d_stage = nullptr; size_t stage_bytes = 0;
+  // sharded map: SUM all-reduce of n doubles in HBM over the ranks, stream-ordered (set by the context); d_gc = its 2-double scratch
+  std::function<int(double *, size_t)> allreduce;
+  double *d_gc = nullptr;
 };
 
 inline void map_init(MapStore &s, const vba_options &o) {
@@ -996,7 +1101,7 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
   return {
       {(void **)&v.nkey, 8, 1}, {(void **)&v.nroot, 4, 1}, {(void **)&v.nparent, 4, 1}, {(void **)&v.nchild, 4, 1}, {(void **)&v.npath, 4, 1},
       {(void **)&v.nopt, 4, 1}, {(void **)&v.nflist, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
-      {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
+      {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nfree_root, 4, 1}, {(void **)&v.nfree_blk, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
       {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
       {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, 8, (size_t)10 * W},
@@ -1026,7 +1131,7 @@ inline int map_read_counters(MapStore &s, hipStream_t st, std::string &err) {
   MAPCHK(hipStreamSynchronize(st));     // drain first: a D2H copy queued behind in-flight kernels completes much later (measured)
   MAPCHK(hipMemcpyAsync(s.h_cnt, s.v.cnt, CNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
   MAPCHK(hipStreamSynchronize(st));
-  s.ub_nodes = s.h_cnt[CNT_NODES]; s.ub_roots = s.h_cnt[CNT_ROOTS]; s.cnt_stale = false;
+  s.ub_nodes = s.h_cnt[CNT_NODES]; s.ub_roots = s.h_cnt[CNT_ROOTS]; s.ub_used = s.h_cnt[CNT_USED]; s.cnt_stale = false;
   return VBA_OK;
 }
 
@@ -1038,8 +1143,10 @@ inline int map_hash_alloc(MapStore &s, unsigned int cap, hipStream_t st, std::st
   MAPCHK(hipMemsetAsync(nv, 0xFF, (size_t)cap * 4, st));
   if (s.v.hkeys) {
     hipLaunchKernelGGL(k_rehash, dim3((s.hcap + 255) / 256), dim3(256), 0, st, s.v.hkeys, s.v.hvals, s.v.hmask, nk, nv, cap - 1);
+    hipLaunchKernelGGL(k_copy_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_ROOTS, (int)CNT_USED);   // the tombstones are gone
     MAPCHK(hipStreamSynchronize(st));
     hipFree(s.v.hkeys); hipFree(s.v.hvals);
+    s.ub_used = s.ub_roots;
   }
   s.v.hkeys = nk; s.v.hvals = nv; s.v.hmask = cap - 1; s.hcap = cap;
   return VBA_OK;
@@ -1052,7 +1159,10 @@ inline int map_base(MapStore &s, hipStream_t st, std::string &err) {
   MAPCHK(hipMalloc((void **)&s.v.poses, VBA_MAX_WIN * 12 * sizeof(double)));
   MAPCHK(hipHostMalloc((void **)&s.h_cnt, CNT_N * sizeof(int) + 64, hipHostMallocDefault));
   std::memset(s.h_cnt, 0, CNT_N * sizeof(int) + 64);
-  int st2 = map_hash_alloc(s, 1u << 20, st, err);
+  // initial root table: 2^20 slots, or (with the max_points_per_scan capacity hint) the power of two above 4x the hint
+  unsigned int hc = 1u << 20;
+  if (s.opt.max_points_per_scan) { hc = 1u << 10; while ((size_t)hc < 4 * s.opt.max_points_per_scan && hc < (1u << 30)) hc *= 2; }
+  int st2 = map_hash_alloc(s, hc, st, err);
   if (st2) return st2;
   s.allocated = true;
   return VBA_OK;
@@ -1088,11 +1198,16 @@ inline int map_ensure(MapStore &s, hipStream_t st, size_t need_nodes, size_t nee
     if (r) return r;
     s.v.cap_fix = (int)nc;
   }
-  // keep the hash table under ~50 % load
-  const size_t want = 2 * ((size_t)s.ub_roots + need_pts);
-  while ((size_t)s.hcap < want && s.hcap < (1u << 30)) {
-    int r = map_hash_alloc(s, s.hcap * 2, st, err);
-    if (r) return r;
+  // keep the hash table under ~50 % load, counting the tombstones of pruned roots (insertion reuses them, lookups walk past
+  // them): when the live roots alone would fit, the table is re-hashed at its current size, which drops the tombstones
+  if (2 * ((size_t)s.ub_used + need_pts) > (size_t)s.hcap) {
+    if (s.cnt_stale) { int r = map_read_counters(s, st, err); if (r) return r; }
+    if (2 * ((size_t)s.ub_used + need_pts) > (size_t)s.hcap) {
+      unsigned int nc = s.hcap;
+      while ((size_t)nc < 2 * ((size_t)s.ub_roots + need_pts) && nc < (1u << 30)) nc *= 2;
+      int r = map_hash_alloc(s, nc, st, err);
+      if (r) return r;
+    }
   }
   return VBA_OK;
 }
@@ -1111,6 +1226,7 @@ inline void map_free(MapStore &s) {
   if (s.h_pose_ring) hipHostFree(s.h_pose_ring);
   for (int i = 0; i < 8; i++) if (s.pose_ev[i]) hipEventDestroy(s.pose_ev[i]);
   if (s.d_stage) hipFree(s.d_stage);
+  if (s.d_gc) { hipFree(s.d_gc); s.d_gc = nullptr; }
   s.v = MapView{};
   s.allocated = false;
 }
@@ -1128,10 +1244,19 @@ inline int map_stage(MapStore &s, size_t bytes, std::string &err) {
   s.stage_bytes = bytes;
   return VBA_OK;
 }
-__global__ void k_set_counter(int *cnt, int which, int val) { cnt[which] = val; }
-__global__ void k_copy_counter(int *cnt, int from, int to) { cnt[to] = cnt[from]; }
 inline int map_set_counter(MapStore &s, hipStream_t st, int which, int val, std::string &err) {   // stream-ordered, no host sync
   hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, which, val);
+  MAPCHK(hipGetLastError());
+  return VBA_OK;
+}
+
+// cnt[to] = sum over the ranks of cnt[from]  (no-op for an unsharded map)
+inline int map_global_count(MapStore &s, hipStream_t st, int from, int to, std::string &err) {
+  if (s.n_ranks <= 1 || !s.allreduce) return VBA_OK;
+  if (!s.d_gc) MAPCHK(hipMalloc((void **)&s.d_gc, 2 * sizeof(double)));
+  hipLaunchKernelGGL(k_cnt_to_f64, dim3(1), dim3(1), 0, st, s.v.cnt, from, s.d_gc);
+  if (s.allreduce(s.d_gc, 1)) { err = "collective failed while summing a map counter over the ranks"; return VBA_ERR_HIP; }
+  hipLaunchKernelGGL(k_f64_to_cnt, dim3(1), dim3(1), 0, st, s.d_gc, s.v.cnt, to);
   MAPCHK(hipGetLastError());
   return VBA_OK;
 }
@@ -1143,7 +1268,7 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   if (win_count < 0 || win_count >= W || n < 0 || !pose || (n > 0 && !pnt_body)) return VBA_ERR_BAD_ARG;
   int r = map_base(s, st, err);
   if (r) return r;
-  if (s.cnt_stale && (s.ub_nodes + n + 64 > (long long)s.v.cap || 2 * (s.ub_roots + n) > (long long)s.hcap)) {
+  if (s.cnt_stale && (s.ub_nodes + n + 64 > (long long)s.v.cap || 2 * (s.ub_used + n) > (long long)s.hcap)) {
     r = map_read_counters(s, st, err);      // bounds too pessimistic for the current capacity: fetch the true counts
     if (r) return r;
   }
@@ -1187,10 +1312,11 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   s.stamp++;
   hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, 0, s.stamp);
   hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0, s.stamp);
+  if (multi) { r = map_global_count(s, st, CNT_TOUCH, CNT_TOUCH_G, err); if (r) return r; }   // VM:2044 tests the whole scan's voxel count
   hipLaunchKernelGGL(k_ins_accum, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0, var ? 1 : 0);
   MAPCHK(hipGetLastError());
   // no read-back: capacity was reserved for the worst case (n new roots), so this call cannot overflow
-  s.ub_nodes += n; s.ub_roots += n; s.cnt_stale = true;
+  s.ub_nodes += n; s.ub_roots += n; s.ub_used += n; s.cnt_stale = true;
   if (!is_device_ptr(pnt_body) || cov6) MAPCHK(hipStreamSynchronize(st));   // the caller's host buffers may go away
   return VBA_OK;
 }
@@ -1232,9 +1358,11 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
   *n_factors = 0;
   if (win_count < 0 || win_count > W || !poses) return VBA_ERR_BAD_ARG;
   if (!s.allocated) return VBA_OK;
+  if (multi) { int r0 = map_global_count(s, st, CNT_SLIDE, CNT_SLIDE_G, err); if (r0) return r0; }   // VS:1693 tests surf_map_slide.size() of the whole map
   for (int attempt = 0; attempt < 8; attempt++) {
     int r = map_read_counters(s, st, err);
     if (r) return r;
+    if (attempt == 0 && s.h_cnt[CNT_OVERFLOW] == 4) { err = "root hash table full during scan insertion"; return VBA_ERR_CAPACITY; }
     // room for every current leaf to split once per level (checked again through the overflow flag)
     r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + 8 * (size_t)(attempt ? s.h_cnt[CNT_NODES] : 65536), 0, 0, err);
     if (r) return r;
@@ -1290,7 +1418,8 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   if (win_count < 1 || win_count > W || !poses) return VBA_ERR_BAD_ARG;
   if (!s.allocated) return VBA_OK;
   int r = VBA_OK;
-  if (s.cnt_stale) { r = map_read_counters(s, st, err); if (r) return r; }    // (the recut before the optimisation left them current)
+  r = map_global_count(s, st, CNT_SLIDE, CNT_SLIDE_G, err); if (r) return r;   // VS:1616 tests the whole sliding map (every rank enters this collective)
+  if (s.cnt_stale || s.n_ranks > 1) { r = map_read_counters(s, st, err); if (r) return r; }    // (the recut before the optimisation left them current)
   const int slot0 = s.mp[0];
   r = map_ensure(s, st, 0, 0, (size_t)s.h_cnt[CNT_FIX] + (size_t)s.npts[slot0] + 1, err);
   if (r) return r;
@@ -1298,7 +1427,7 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   MAPCHK(hipMemcpyAsync(s.v.poses, poses, (size_t)win_count * 12 * sizeof(double), hipMemcpyHostToDevice, st));
   const MapParams P = map_params(s);
   const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
-  const int n_slide_before = s.h_cnt[CNT_SLIDE];
+  const int n_slide_before = s.n_ranks > 1 ? s.h_cnt[CNT_SLIDE_G] : s.h_cnt[CNT_SLIDE];
   if (nn == 0) return VBA_OK;
   s.epoch++;
   const dim3 gn((nn + 255) / 256), b(256);
@@ -1340,7 +1469,7 @@ inline int map_reset(MapStore &s, hipStream_t st, std::string &err) {
   MAPCHK(hipStreamSynchronize(st));
   std::memset(s.h_cnt, 0, CNT_N * sizeof(int));
   for (int i = 0; i < VBA_MAX_WIN; i++) { s.mp[i] = i; s.npts[i] = 0; }
-  s.have_var = false; s.ub_nodes = 0; s.ub_roots = 0; s.cnt_stale = false;
+  s.have_var = false; s.ub_nodes = 0; s.ub_roots = 0; s.ub_used = 0; s.cnt_stale = false;
   return VBA_OK;
 }
 
@@ -1349,6 +1478,18 @@ inline int map_num_roots(MapStore &s, hipStream_t st, bool slide) {
   std::string err;
   if (map_read_counters(s, st, err)) return -1;
   return slide ? s.h_cnt[CNT_SLIDE] : s.h_cnt[CNT_ROOTS];
+}
+
+// storage statistics: [node high-water mark, free root nodes, free child blocks, hash capacity, hash slots in use (roots +
+// tombstones), roots, sliding-map roots, fixed points]
+inline int map_stats(MapStore &s, hipStream_t st, long long *out8, std::string &err) {
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  if (!s.allocated) return VBA_OK;
+  int r = map_read_counters(s, st, err);
+  if (r) return r;
+  out8[0] = s.h_cnt[CNT_NODES]; out8[1] = s.h_cnt[CNT_FREE_ROOTS]; out8[2] = s.h_cnt[CNT_FREE_BLOCKS]; out8[3] = s.hcap;
+  out8[4] = s.h_cnt[CNT_USED]; out8[5] = s.h_cnt[CNT_ROOTS]; out8[6] = s.h_cnt[CNT_SLIDE]; out8[7] = s.h_cnt[CNT_FIX];
+  return VBA_OK;
 }
 
 inline int map_dump_leaves(MapStore &s, hipStream_t st, double *out, int max_leaves, std::string &err) {
@@ -1370,6 +1511,25 @@ inline int map_dump_leaves(MapStore &s, hipStream_t st, double *out, int max_lea
   return n;
 }
 
+inline int map_dump_plane_var(MapStore &s, hipStream_t st, double *out, int max_leaves, std::string &err) {
+  if (!s.allocated) return 0;
+  if (map_read_counters(s, st, err)) return -1;
+  const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
+  if (nn == 0) return 0;
+  const int cap_out = out ? max_leaves : 0;
+  double *d_out = nullptr;
+  if (cap_out > 0 && hipMalloc((void **)&d_out, (size_t)cap_out * 86 * 8) != hipSuccess) return -1;
+  if (map_set_counter(s, st, CNT_LEAVES, 0, err)) return -1;
+  hipLaunchKernelGGL(k_dump_plane_var, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, d_out, cap_out);
+  if (map_read_counters(s, st, err)) return -1;
+  const int n = s.h_cnt[CNT_LEAVES];
+  if (cap_out > 0) {
+    hipMemcpy(out, d_out, (size_t)(n < cap_out ? n : cap_out) * 86 * 8, hipMemcpyDeviceToHost);
+    hipFree(d_out);
+  }
+  return n;
+}
+
 inline int map_prune(MapStore &s, hipStream_t st, double jour, int dist, std::string &err) {
   if (!s.allocated) return VBA_OK;
   int r = map_read_counters(s, st, err);
@@ -1380,6 +1540,7 @@ inline int map_prune(MapStore &s, hipStream_t st, double jour, int dist, std::st
   hipLaunchKernelGGL(k_prune_roots, dim3((s.hcap + 255) / 256), dim3(256), 0, st, s.v, jour, dist, s.epoch);
   hipLaunchKernelGGL(k_prune_nodes, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, s.epoch);
   hipLaunchKernelGGL(k_prune_finish, dim3((nn + 255) / 256), dim3(256), 0, st, s.v, s.epoch);
+  hipLaunchKernelGGL(k_prune_zero, dim3((nn + 255) / 256, 130 + 10 * s.opt.win_size), dim3(256), 0, st, s.v, s.opt.win_size, s.epoch);
   if (s.h_cnt[CNT_FIX] > 0) hipLaunchKernelGGL(k_prune_fix, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v);
   MAPCHK(hipGetLastError());
   return map_read_counters(s, st, err);

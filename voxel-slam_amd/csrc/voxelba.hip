@@ -17,6 +17,7 @@
 #include "vba_hostmath.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,6 +52,7 @@ struct vba_ctx {
   // factor store (HBM, SoA)
   FactorView fv{};
   int nvox = 0;   // voxels stored
+  int nvox_global = 0;   // the same summed over the ranks (set by vba_lm_begin when the factor store is sharded)
   int cap = 0;    // capacity = stride
   double *d_poses = nullptr;     // [W][12]
   double *d_partial = nullptr;   // workgroup partials
@@ -68,7 +70,10 @@ struct vba_ctx {
   void *allreduce_user = nullptr;
   int rank = 0, n_ranks = 1;
   bool force_collective = std::getenv("VBA_FORCE_COLLECTIVE") != nullptr;   // rehearsal: run the exchange step with one rank
-  bool collective() const { return allreduce && (n_ranks > 1 || force_collective); }
+  ncclComm_t comm = nullptr;      // RCCL communicator: the exchange step is issued by the library on the context's stream
+  bool own_comm = false;
+  bool collective_off = false;    // replica phases (bottom-layer HBA windows) run their LM loops without the exchange step
+  bool collective() const { return !collective_off && (allreduce || comm) && (n_ranks > 1 || force_collective); }
 
   // timing
   bool timing = false;
@@ -84,6 +89,7 @@ struct vba_ctx {
   int lm_up_next = 0;
   double *d_raw = nullptr;        // last valid all-reduced [H|g|r] (multi-rank only; single rank reads d_out in place)
   struct { bool active = false; int thd_num = 2; bool have_hess = false; bool pending_update = false; int k4_nb = 0; } lm;   // pending_update: the accept/reject step of the last iteration rides in the next Hessian pass
+  int k4part_cap = 0;
   double *d_k4part = nullptr;     // residual-pass partials of the LM loop (the Hessian pass reuses d_partial while they are still read)   // have_hess: [H|g|r] of the next solve is already reduced (multi-rank)
   std::vector<double> trace;
 
@@ -234,38 +240,71 @@ int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int 
   }
 }
 
-void k4_stamps_dump(vba_ctx *c, int nb, bool before) {
-  static long long *d_st = nullptr;
-  if (before) {
-    if (!d_st) { hipMalloc((void **)&d_st, 512 * 4 * 8); hipMemcpyToSymbol(HIP_SYMBOL(g_k4_stamps), &d_st, sizeof(d_st)); }
-    hipMemsetAsync(d_st, 0, 512 * 4 * 8, c->stream);
-    return;
-  }
-  std::vector<long long> h(512 * 4);
+#ifndef VBA_K4_TV
+#define VBA_K4_TV 32        // voxels per workgroup of the residual pass (tools/ builds 16 / 64 for comparison)
+#endif
+// number of workgroups (= residual partials) of the residual pass over n voxels
+inline int residual_nb(int n) { return (n + VBA_K4_TV - 1) / VBA_K4_TV; }
+
+// diagnostic (VBA_K4_STAMPS=1): in-kernel clock stamps of a separate STAMPS instantiation; the production kernel holds none
+void k4_stamps_dump(vba_ctx *c, int nb, long long *d_st) {
+  const int n = nb < 2048 ? nb : 2048;
+  std::vector<long long> h((size_t)n * 4);
   hipStreamSynchronize(c->stream);
   hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
   long long t0 = h[0];
-  const int n = nb < 512 ? nb : 512;
   for (int b = 0; b < n; b++) if (h[b * 4] && h[b * 4] < t0) t0 = h[b * 4];
   double a = 0, e = 0, w = 0, last = 0;
   for (int b = 0; b < n; b++) { a += h[b * 4 + 1] - h[b * 4]; e += h[b * 4 + 2] - h[b * 4 + 1]; w += h[b * 4 + 3] - h[b * 4 + 2]; if (h[b * 4 + 3] - t0 > last) last = h[b * 4 + 3] - t0; }
-  fprintf(stderr, "[k4 stamps] %d waves: loads+transforms %.0f, eigen %.0f, stores+reduce %.0f cycles (mean per wave); last wave ends at %.0f cycles\n", n, a / n, e / n, w / n, last);
+  fprintf(stderr, "[k4 stamps] %d workgroups: loads+transforms %.0f, frame sum + eigen %.0f, stores+reduce %.0f cycles (mean per workgroup); last one ends at %.0f cycles\n", n, a / n, e / n, w / n, last);
 }
 
-void launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, int nb, double *dst = nullptr) {
+// residual pass over voxels [head, end) (end > head); partials (one per workgroup) go to dst or d_partial; returns their number
+int launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, double *dst = nullptr) {
   double *part = dst ? dst : c->d_partial;
-  static const bool want_stamps = getenv("VBA_K4_STAMPS") != nullptr;   // diagnostic switch, off in production
-  if (want_stamps) k4_stamps_dump(c, nb, true);
-  // below ~1 wave per SIMD the pass is latency-bound: one load batch; above it, two batches for 4-wave occupancy
-  const bool big = nb > 2048;
-#define VBA_RES_CASE(WW) case WW: if (big) hipLaunchKernelGGL((k_residual_w<WW, 3>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate); \
-    else hipLaunchKernelGGL((k_residual_w<WW, 1>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate); break;
+  const int nb = residual_nb(end - head);
+  static const bool want_stamps = getenv("VBA_K4_STAMPS") != nullptr;
+  static long long *d_st = nullptr;
+  if (want_stamps) {
+    if (!d_st) hipMalloc((void **)&d_st, 2048 * 4 * 8);
+    hipMemsetAsync(d_st, 0, 2048 * 4 * 8, c->stream);
+  }
+#define VBA_RES_CASE(WW) case WW: { using RC = ResCfg<WW, VBA_K4_TV>; \
+    if (want_stamps) hipLaunchKernelGGL((k_residual_s<WW, VBA_K4_TV, true>), dim3(nb), dim3(RC::NT), 0, c->stream, c->fv, pd, head, end, part, gate, d_st); \
+    else hipLaunchKernelGGL((k_residual_s<WW, VBA_K4_TV, false>), dim3(nb), dim3(RC::NT), 0, c->stream, c->fv, pd, head, end, part, gate, (long long *)nullptr); break; }
   switch (c->opt.win_size) {
-    VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(8) VBA_RES_CASE(10) VBA_RES_CASE(12)
-    default: hipLaunchKernelGGL(k_residual, dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate);
+    VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(7) VBA_RES_CASE(8) VBA_RES_CASE(9) VBA_RES_CASE(10)
+    VBA_RES_CASE(11) VBA_RES_CASE(12) VBA_RES_CASE(13) VBA_RES_CASE(14) VBA_RES_CASE(15) VBA_RES_CASE(16)
   }
 #undef VBA_RES_CASE
-  if (want_stamps) k4_stamps_dump(c, nb, false);
+  if (want_stamps) k4_stamps_dump(c, nb, d_st);
+  return nb;
+}
+
+// SUM all-reduce of n doubles in HBM across the ranks, ordered on the context's stream: RCCL when the context holds a
+// communicator (vba_rccl_init / vba_set_rccl_comm), else the host program's hook (gloo rehearsals on the CPU side of tests).
+int ctx_allreduce(vba_ctx *c, double *buf, size_t n) {
+  if (c->comm) {
+    const ncclResult_t r = ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) { c->set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return VBA_ERR_HIP; }
+    return VBA_OK;
+  }
+  if (!c->allreduce) { c->set_error("no collective configured"); return VBA_ERR_BAD_ARG; }
+  if (c->allreduce(c->allreduce_user, buf, n, c->stream)) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
+  return VBA_OK;
+}
+// All-gather in place: buf holds n_ranks chunks of `chunk` doubles, rank r has filled chunk r.  RCCL moves every chunk once;
+// the hook (SUM only) emulates it by zeroing the foreign chunks first.
+int ctx_allgather(vba_ctx *c, double *buf, size_t chunk) {
+  if (chunk == 0) return VBA_OK;
+  if (c->comm) {
+    const ncclResult_t r = ncclAllGather(buf + (size_t)c->rank * chunk, buf, chunk, ncclDouble, c->comm, c->stream);
+    if (r != ncclSuccess) { c->set_error(std::string("ncclAllGather: ") + ncclGetErrorString(r)); return VBA_ERR_HIP; }
+    return VBA_OK;
+  }
+  for (int r = 0; r < c->n_ranks; r++)
+    if (r != c->rank) HIPCHK(c, hipMemsetAsync(buf + (size_t)r * chunk, 0, chunk * sizeof(double), c->stream));
+  return ctx_allreduce(c, buf, chunk * (size_t)c->n_ranks);
 }
 
 // device passes on device-resident poses (gate == nullptr: unconditional)
@@ -286,8 +325,8 @@ int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head,
     HIPCHK(c, hipGetLastError());
   }
   if (c->collective()) {
-    int rc = c->allreduce(c->allreduce_user, c->d_out, (size_t)nout, c->stream);
-    if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
+    int rc = ctx_allreduce(c, c->d_out, (size_t)nout);
+    if (rc) return rc;
   }
   return VBA_OK;
 }
@@ -296,11 +335,11 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(d_scalar_out, 0, sizeof(double), c->stream));
   } else {
-    const int nb = (end - head + 63) / 64;
+    const int nb = residual_nb(end - head);
     if ((size_t)nb > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
     TimedSpan s1{}, s2{};
     span_begin(c, "residual", s1);
-    launch_residual(c, poses_dev, gate, head, end, nb);
+    launch_residual(c, poses_dev, gate, head, end);
     span_end(c, "residual", s1);
     span_begin(c, "reduce", s2);
     hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, c->stream, c->d_partial, nb, d_scalar_out, gate);
@@ -308,8 +347,8 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
     HIPCHK(c, hipGetLastError());
   }
   if (c->collective()) {
-    int rc = c->allreduce(c->allreduce_user, d_scalar_out, 1, c->stream);
-    if (rc) { c->set_error("allreduce hook failed"); return VBA_ERR_HIP; }
+    int rc = ctx_allreduce(c, d_scalar_out, 1);
+    if (rc) return rc;
   }
   return VBA_OK;
 }
@@ -437,6 +476,7 @@ void vba_destroy(vba_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm && c->own_comm) ncclCommDestroy(c->comm);
   map_free(c->map);
   c->gba.free_all();
   c->big.release();
@@ -583,6 +623,21 @@ int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   HIPCHK(c, hipEventRecord(c->lm_up_ev[slot], c->stream));
   c->lm.active = true; c->lm.thd_num = thd_num; c->lm.have_hess = false; c->lm.pending_update = false;
   c->trace.clear();
+  // "Too Less Voxel" (VM:399-403) is a statement about the whole window: a sharded rank decides it from the voxel count summed over
+  // the ranks, so every rank takes the same branch and none is left waiting in the next collective
+  c->nvox_global = c->nvox;
+  if (c->collective()) {
+    int st = ensure_pin(c, 65536);
+    if (st) return st;
+    c->h_pin[60000] = (double)c->nvox;
+    HIPCHK(c, hipMemcpyAsync(c->d_scal + 8, c->h_pin + 60000, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    st = ctx_allreduce(c, c->d_scal + 8, 1);
+    if (st) return st;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + 60000, c->d_scal + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nvox_global = (int)(c->h_pin[60000] + 0.5);
+  }
   return VBA_OK;
 }
 
@@ -599,7 +654,7 @@ int vba_lm_refresh_eigen(vba_ctx *c) {
 int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   if (!c->lm.active) return VBA_ERR_BAD_ARG;
   const int W = c->opt.win_size, nout = nout_of(W), V = c->nvox;
-  if (V < c->lm.thd_num) return VBA_ERR_TOO_FEW_VOXELS;               // VM:399-403 (and g_size checks of VM:367)
+  if (c->nvox_global < c->lm.thd_num) return VBA_ERR_TOO_FEW_VOXELS;   // VM:399-403 (and g_size checks of VM:367); the same on every rank
   char *base = reinterpret_cast<char *>(c->d_lm);
   const double *x_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, x));
   const double *xt_dev = reinterpret_cast<const double *>(base + offsetof(LmDev, xt));
@@ -654,18 +709,23 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   span_end(c, "solve", sp);
   double *d_r = c->d_scal;
   if (copy_raw) {
-    if (V > 0) launch_residual(c, xt_dev, run_res, 0, V, (V + 63) / 64);   // only_residual VM:467: refreshes the eigen state at the trial poses
+    if (V > 0) launch_residual(c, xt_dev, run_res, 0, V);   // only_residual VM:467: refreshes the eigen state at the trial poses
     st = hessian_pass(c, xt_dev, run_res, 0, V);                      // speculative divide_thread there + the one all-reduce
     if (st) return st;
     c->lm.have_hess = true;
     hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out + (nout_tl(W) - 1), 0, W);
   } else {
-    const int nb = (V + 63) / 64;
-    if (!c->d_k4part) HIPCHK(c, hipMalloc((void **)&c->d_k4part, (size_t)65536 * sizeof(double)));
-    const bool fuse = !no_fuse && nb <= 65536 && !(accepted || stop);
+    const int nb = residual_nb(V);
+    if (nb > c->k4part_cap) {
+      if (c->d_k4part) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_k4part); c->d_k4part = nullptr; }
+      const int cap = nb > 65536 ? 2 * nb : 65536;
+      HIPCHK(c, hipMalloc((void **)&c->d_k4part, (size_t)cap * sizeof(double)));
+      c->k4part_cap = cap;
+    }
+    const bool fuse = !no_fuse && !(accepted || stop);
     TimedSpan s1{};
     span_begin(c, "residual", s1);
-    launch_residual(c, xt_dev, run_res, 0, V, nb, c->d_k4part);
+    launch_residual(c, xt_dev, run_res, 0, V, c->d_k4part);
     span_end(c, "residual", s1);
     if (fuse) { c->lm.pending_update = true; c->lm.k4_nb = nb; }
     else hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_k4part, nb, W);   // sums the partials itself
@@ -834,7 +894,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     }
     span_end(c, "solve", s1);
     if (copy_raw) {                                                   // one collective per iteration (see vba_lm_iterate)
-      if (V > 0) launch_residual(c, xt_dev, run_res, 0, V, (V + 63) / 64);
+      if (V > 0) launch_residual(c, xt_dev, run_res, 0, V);
       st = hessian_pass(c, xt_dev, run_res, 0, V);
       if (st) { c->lm.active = false; return st; }
       c->lm.have_hess = true;
@@ -844,10 +904,10 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
       if (st) { c->lm.active = false; return st; }
       hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_scal, 0);
     } else {
-      const int nbk = (V + 63) / 64;
+      const int nbk = residual_nb(V);
       TimedSpan s2{};
       span_begin(c, "residual", s2);
-      launch_residual(c, xt_dev, run_res, 0, V, nbk);
+      launch_residual(c, xt_dev, run_res, 0, V);
       span_end(c, "residual", s2);
       hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_partial, nbk);
     }
@@ -1423,14 +1483,29 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     n_sub_cap += nw; if (nw > n_win_max) n_win_max = nw;
   }
   // More than one rank ("windows are independent problems => replicas across GPUs for the bottom layer"): window
-  // wi is optimised by rank wi % n_ranks with the collective switched off; every rank writes its windows' clouds at fixed
-  // offsets of a zeroed buffer and its edges into a zeroed record table, and ONE sum all-reduce of each is the gather.  The
-  // top-level window then runs replicated (identical inputs on every rank).
+  // wi is optimised by rank wi % n_ranks with the exchange step switched off; every rank packs its windows' clouds and its
+  // [points, edges, status | edge rows] records into ITS chunk of two buffers, and one ALL-GATHER of each hands every rank all of
+  // them (a rank receives each foreign byte once).  A window that fails on one rank travels as its status word: every rank
+  // enters both collectives and all of them return the same error afterwards — no rank is left waiting in a collective.
+  // The top-level window then runs replicated (identical inputs on every rank).
   const bool replicas = c->collective() && c->n_ranks > 1;
+  const int NR = replicas ? c->n_ranks : 1;
   int n_win = 0;
   for (int start = 0; start + wdsize <= n_kf; start += mgsize) n_win++;
-  const size_t meta_per = 2 + (size_t)(wdsize * (wdsize - 1) / 2) * 20, n_meta = replicas ? meta_per * (size_t)n_win : 0;
-  const size_t need = (n_all + (replicas ? 2 : 1) * n_sub_cap) * 3 + n_meta + 64;
+  const size_t meta_per = 3 + (size_t)(wdsize * (wdsize - 1) / 2) * 20;
+  const size_t win_per_rank = replicas ? (size_t)(n_win + NR - 1) / NR : 0, meta_chunk = meta_per * win_per_rank;
+  std::vector<size_t> rank_cap(NR, 0), win_roff(n_win > 0 ? n_win : 1, 0);      // points capacity per rank chunk, window offset inside it
+  if (replicas) {
+    int w = 0;
+    for (int start = 0; start + wdsize <= n_kf; start += mgsize, w++) {
+      win_roff[w] = rank_cap[w % NR];
+      rank_cap[w % NR] += (size_t)(offsets[start + wdsize] - offsets[start]);
+    }
+  }
+  size_t chunk_pts = 0;
+  for (int r = 0; r < NR; r++) if (rank_cap[r] > chunk_pts) chunk_pts = rank_cap[r];
+  if (!replicas) chunk_pts = 0;
+  const size_t need = (n_all + n_sub_cap + (size_t)NR * chunk_pts) * 3 + (size_t)NR * meta_chunk + 64;
   if (need > c->hba_all_doubles) {
     if (c->d_hba_all) hipFree(c->d_hba_all);
     c->d_hba_all = nullptr; c->hba_all_doubles = 0;
@@ -1441,17 +1516,11 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   if (n_all > 0) HIPCHK(c, hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream));
   std::vector<int> ccnt(n_win_max > 0 ? n_win_max : 1);
   size_t sub_off = 0;
-  double *d_rep = d_sub + n_sub_cap * 3, *d_meta = d_rep + n_sub_cap * 3;      // replica mode only
-  std::vector<double> meta(n_meta, 0.0);
-  std::vector<size_t> cap_off;
-  const vba_allreduce_fn hook = c->allreduce;
-  if (replicas) {
-    HIPCHK(c, hipMemsetAsync(d_rep, 0, n_sub_cap * 3 * sizeof(double), c->stream));
-    c->allreduce = nullptr;                                                    // the windows' own LM loops must not enter a collective
-  }
-  struct Restore { vba_ctx *c; vba_allreduce_fn h; ~Restore() { c->allreduce = h; } } restore{c, hook};
+  double *d_rep = d_sub + n_sub_cap * 3, *d_meta = d_rep + (size_t)NR * chunk_pts * 3;      // replica mode only
+  std::vector<double> meta((size_t)NR * meta_chunk, 0.0);
+  struct Restore { vba_ctx *c; bool was; ~Restore() { c->collective_off = was; } } restore{c, c->collective_off};
+  if (replicas) c->collective_off = true;                                       // the windows' own LM loops must not enter a collective
   int wi = -1;
-  size_t cap_run = 0;
   static const bool want_times = getenv("VBA_HBA_TIMES") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_g0 = want_times ? (hipStreamSynchronize(c->stream), now()) : 0.0;
@@ -1463,16 +1532,17 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     int ne = 0, nc = 0;
     wi++;
     if (replicas) {
-      cap_off.push_back(cap_run);
-      cap_run += (size_t)off[wdsize];
       sub_first.push_back(start);
-      if (wi % c->n_ranks != c->rank) continue;
-      int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
-                                gba_eigen_value_array, 1, 2, edges.data(), &ne, d_rep + cap_off.back() * 3, ccnt.data(), &nc, nullptr, nullptr);
-      if (st) return st;
-      double *mrec = &meta[meta_per * (size_t)wi];
-      mrec[0] = nc; mrec[1] = ne;
-      std::memcpy(mrec + 2, edges.data(), (size_t)ne * 20 * sizeof(double));
+      if (wi % NR != c->rank) continue;
+      double *mrec = &meta[(size_t)c->rank * meta_chunk + meta_per * (size_t)(wi / NR)];
+      const int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
+                                      gba_eigen_value_array, 1, 2, edges.data(), &ne, d_rep + ((size_t)c->rank * chunk_pts + win_roff[wi]) * 3,
+                                      ccnt.data(), &nc, nullptr, nullptr);
+      mrec[2] = st;                            // travels with the gather: every rank learns it
+      if (st == VBA_OK) {
+        mrec[0] = nc; mrec[1] = ne;
+        std::memcpy(mrec + 3, edges.data(), (size_t)ne * 20 * sizeof(double));
+      }
       continue;
     }
     int st = vba_hba_add_edge(c, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
@@ -1490,25 +1560,35 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     sub_off += (size_t)nc;
   }
   if (replicas) {
-    // gather: sum of the zero-padded per-rank buffers
-    HIPCHK(c, hipMemcpyAsync(d_meta, meta.data(), n_meta * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (hook(c->allreduce_user, d_rep, n_sub_cap * 3, c->stream) || hook(c->allreduce_user, d_meta, n_meta, c->stream)) {
-      c->set_error("allreduce hook failed"); return VBA_ERR_HIP;
-    }
+    c->collective_off = restore.was;
+    if (meta_chunk > 0)
+      HIPCHK(c, hipMemcpyAsync(d_meta + (size_t)c->rank * meta_chunk, meta.data() + (size_t)c->rank * meta_chunk, meta_chunk * sizeof(double),
+                               hipMemcpyHostToDevice, c->stream));
+    int rc = ctx_allgather(c, d_rep, chunk_pts * 3);
+    if (rc) return rc;
+    rc = ctx_allgather(c, d_meta, meta_chunk);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, n_meta * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, meta.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int worst = VBA_OK;
     for (int w = 0; w < n_win; w++) {
-      const double *mrec = &meta[meta_per * (size_t)w];
+      const int stw = (int)meta[(size_t)(w % NR) * meta_chunk + meta_per * (size_t)(w / NR) + 2];
+      if (stw != VBA_OK && worst == VBA_OK) worst = stw;
+    }
+    if (worst != VBA_OK) { c->set_error("a bottom-layer window failed on one of the ranks"); return worst; }   // the same on every rank
+    for (int w = 0; w < n_win; w++) {
+      const double *mrec = &meta[(size_t)(w % NR) * meta_chunk + meta_per * (size_t)(w / NR)];
       const int nc = (int)mrec[0], ne = (int)mrec[1], start = sub_first[w];
       for (int e = 0; e < ne; e++) {
         if (*n_edges1 >= cap1) return VBA_ERR_CAPACITY;
         double *o = edges1_out + (size_t)(*n_edges1) * 20;
-        std::memcpy(o, mrec + 2 + (size_t)e * 20, 20 * sizeof(double));
+        std::memcpy(o, mrec + 3 + (size_t)e * 20, 20 * sizeof(double));
         o[0] += start; o[1] += start;
         (*n_edges1)++;
       }
-      if (nc > 0) HIPCHK(c, hipMemcpyAsync(d_sub + sub_off * 3, d_rep + cap_off[w] * 3, (size_t)nc * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (nc > 0) HIPCHK(c, hipMemcpyAsync(d_sub + sub_off * 3, d_rep + ((size_t)(w % NR) * chunk_pts + win_roff[w]) * 3, (size_t)nc * 3 * sizeof(double),
+                                           hipMemcpyDeviceToDevice, c->stream));
       sub_n.push_back(nc);
       sub_off += (size_t)nc;
     }
@@ -1557,6 +1637,34 @@ int vba_imu_give_evaluate(const double *imu_pre, const double *s1, const double 
 
 // ---------------------------------------------------------------- multi-GPU plumbing
 int vba_set_allreduce(vba_ctx *c, vba_allreduce_fn fn, void *user) { c->allreduce = fn; c->allreduce_user = user; return VBA_OK; }
+
+// RCCL inside the library (north_star: "RCCL all-reduce of the (6W)x(6W) Hessian over xGMI"): the communicator lives in the context
+// and ncclAllReduce(ncclDouble, ncclSum) is issued on the context's stream, no host code in the LM loop.
+int vba_rccl_get_unique_id(void *out128) {
+  if (!out128) return VBA_ERR_BAD_ARG;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return VBA_ERR_HIP;
+  std::memcpy(out128, &id, sizeof(id));
+  return VBA_OK;
+}
+int vba_rccl_init(vba_ctx *c, const void *unique_id128, int rank, int n_ranks) {
+  if (!c || !unique_id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return VBA_ERR_BAD_ARG;
+  if (c->comm && c->own_comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id128, sizeof(id));
+  HIPCHK(c, hipSetDevice(c->device));
+  const ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; c->set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return VBA_ERR_HIP; }
+  c->own_comm = true;
+  return vba_set_shard(c, rank, n_ranks);
+}
+int vba_set_rccl_comm(vba_ctx *c, void *nccl_comm) {
+  if (!c) return VBA_ERR_BAD_ARG;
+  if (c->comm && c->own_comm) ncclCommDestroy(c->comm);
+  c->comm = (ncclComm_t)nccl_comm; c->own_comm = false;
+  return VBA_OK;
+}
 int vba_shard_owner(int64_t kx, int64_t ky, int64_t kz, int n_ranks) {
   if (n_ranks <= 1) return 0;
   return (int)(vba::shard_bucket(kx, ky, kz) * (uint64_t)n_ranks >> 16);   // contiguous bucket ranges per rank
@@ -1565,6 +1673,7 @@ int vba_set_shard(vba_ctx *c, int rank, int n_ranks) {
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return VBA_ERR_BAD_ARG;
   c->rank = rank; c->n_ranks = n_ranks;
   c->map.rank = rank; c->map.n_ranks = n_ranks;
+  c->map.allreduce = [c](double *buf, size_t n) { return (c->allreduce || c->comm) ? ctx_allreduce(c, buf, n) : (int)VBA_ERR_BAD_ARG; };
   return VBA_OK;
 }
 
@@ -1760,6 +1869,7 @@ int vba_map_prune(vba_ctx *c, double jour, int dist) { return map_prune(c->map, 
 int vba_map_reset(vba_ctx *c) { return map_reset(c->map, c->stream, c->err); }
 int vba_map_num_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, false); }
 int vba_map_num_slide_roots(vba_ctx *c) { return map_num_roots(c->map, c->stream, true); }
+int vba_map_stats(vba_ctx *c, long long *out8) { return out8 ? map_stats(c->map, c->stream, out8, c->err) : VBA_ERR_BAD_ARG; }
 // ---------------------------------------------------------------- odometry scan-to-map (VS:962-1098)
 int vba_odom_lio_state_estimation(vba_ctx *c, int n, const double *pnt_body, const double *var_body, double *state, double *cov, int *ok) {
   if (n < 0 || (n > 0 && (!pnt_body || !var_body)) || !state || !cov) return VBA_ERR_BAD_ARG;
@@ -1858,6 +1968,7 @@ int vba_odom_lio_state_estimation(vba_ctx *c, int n, const double *pnt_body, con
 }
 
 int vba_map_dump_leaves(vba_ctx *c, double *out, int max_leaves) { return map_dump_leaves(c->map, c->stream, out, max_leaves, c->err); }
+int vba_map_dump_plane_var(vba_ctx *c, double *out, int max_leaves) { return map_dump_plane_var(c->map, c->stream, out, max_leaves, c->err); }
 
 // ---------------------------------------------------------------- session-store formats (vba_io.hpp), host only
 int vba_io_save_pcd(const char *path, int n, const double *xyz) {
