@@ -8,9 +8,11 @@ the window restarts from the perturbed initial poses; the restart's residual pas
 eigen state that recut/tras_opt hand to damping_iter, voxel_map.hpp:1628) runs inside the timed region but is not
 counted as a step.  Inputs (the factor store) are resident in HBM before the timed region.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; voxels are sharded by root-voxel hash bucket
-(vba_shard_owner), each rank evaluates its shard and the packed [H|g|r] buffer is all-reduced (RCCL) — total work is
-fixed, so scaling is "strong".
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one
+rank; called plainly with --gpus N it starts the N rank processes itself (before it touches the GPU) and fails if the node has
+fewer than N devices.  Voxels are sharded by root-voxel hash bucket (vba_shard_owner), each rank evaluates its shard and the packed
+[H|g|r] buffer is summed by the library's own RCCL communicator (vba_rccl_init: ncclAllReduce on the context's stream) — total work
+is fixed, so scaling is "strong".
 """
 import argparse
 import ctypes
@@ -46,25 +48,34 @@ def build_problem(wl_name):
     return wl, s, poses0
 
 
-def cpu_baseline(wl, scans, poses0, budget_s=15.0):
+def cpu_baseline(wl, scans, poses0, budget_s=12.0):
     """The CPU oracle (faithful restatement of the reference path) timed on this host: the window's factors are built
     by the oracle's own octree (cut_voxel x W, recut, tras_opt), then damping_iter(max_iter=3) with the reference's
-    5 std::thread workers (voxel_map.hpp:521) is repeated on them; iterations/s over a bounded sample."""
+    5 std::thread workers (voxel_map.hpp:521) is repeated on them; iterations/s over a bounded sample.  Also timed once
+    each: the per-stage K1 / K2 / K5 work and the LiDAR-inertial optimiser the node runs per scan."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api
     oracle_api.build()
+    from voxel_slam_amd import synth, capi
     W = wl.win_size
     om = oracle_api.VoxelMap(W, wl.voxel_size, wl.max_layer, wl.min_eigen_value, wl.plane_thre, wl.min_point, wl.max_points, 5)
     t0 = time.perf_counter()
+    t_scan = []
     for i in range(W):
-        om.cut_voxel(i, scans["points"][i], poses0[i])
+        t1 = time.perf_counter()
+        om.cut_voxel(i, scans["points"][i], poses0[i], multi=True)
+        t_scan.append(time.perf_counter() - t1)
+    t_ins = time.perf_counter() - t0
     f0 = oracle_api.Factor(W)
-    om.recut(W, poses0, f0, multi=False)
+    t1 = time.perf_counter()
+    om.recut(W, poses0, f0, multi=True)
+    t_recut = time.perf_counter() - t1
     t_build = time.perf_counter() - t0
     fac = f0.as_dict()
     iters = 0
     t_tot = 0.0
     reps = 0
+    n_rej = 0
     while t_tot < budget_s and reps < 50:
         f = oracle_api.Factor(W)
         f.push_dict(fac)
@@ -72,8 +83,9 @@ def cpu_baseline(wl, scans, poses0, budget_s=15.0):
         out = f.lidar_ba_damping_iter(poses0, max_iter=3, thd_num=5, parallel=True)
         t_tot += time.perf_counter() - t0
         iters += len(out["trace"])
+        n_rej += int((out["trace"][:, 1] >= out["trace"][:, 0]).sum())
         reps += 1
-    # courtesy number (SURVEY.md §8d): the same loop with one worker per core of this box's CPU share
+    # courtesy number (SURVEY.md 8d): the same loop with one worker per core of this box's CPU share
     nthr = max(1, min(len(os.sched_getaffinity(0)), 64))
     it_all, t_all, reps_all = 0, 0.0, 0
     while t_all < budget_s / 3 and reps_all < 20:
@@ -84,23 +96,55 @@ def cpu_baseline(wl, scans, poses0, budget_s=15.0):
         t_all += time.perf_counter() - t0
         it_all += len(out["trace"])
         reps_all += 1
+    # LI_BA_Optimizer::damping_iter (voxel_map.hpp:624-713, the call at voxelslam.cpp:1969) on the same factors, 5 threads
+    imu_samples, vel, g = synth.make_imu(wl, gyr_sigma=1e-3, acc_sigma=1e-2)
+    nm = np.array([0.01] * 3 + [1.0] * 3); nw = np.array([1e-4] * 6)
+    imus = np.stack([oracle_api.imu_preintegrate(t, gy, ac, np.zeros(3), np.zeros(3), nm, nw) for (t, gy, ac) in imu_samples])
+    states = np.zeros((W, 25))
+    for i in range(W):
+        states[i, 0] = 0.1 * i; states[i, 1:10] = poses0[i, :9]; states[i, 10:13] = poses0[i, 9:12]; states[i, 13:16] = vel[i]; states[i, 22:25] = g
+    li_it, li_t, li_reps = 0, 0.0, 0
+    while li_t < budget_s / 3 and li_reps < 20:
+        f = oracle_api.Factor(W)
+        f.push_dict(fac)
+        t0 = time.perf_counter()
+        out = f.li_ba_damping_iter(states, imus, gravity=False, imu_coef=wl.imu_coef, max_iter=3, parallel=True)
+        li_t += time.perf_counter() - t0
+        li_it += len(out["trace"])
+        li_reps += 1
+    # K5: multi_margi of the oldest scan on the full map (one call; it consumes the factor store's refined state)
+    t1 = time.perf_counter()
+    om.margi(W, poses0, f0, jour=0.0)
+    t_margi = time.perf_counter() - t1
     return dict(value=iters / t_tot, unit="iterations/s", cores=5, kind="port",
                 all_cores={"value": it_all / t_all, "threads": nthr, "calls": reps_all},
-                sample="%d damping_iter calls (%d LM iterations) on the full %d-voxel window, 5 worker threads of %d host cores; "
-                       "single-thread full-window rebuild (insert+recut, %d pts) took %.2f s"
-                       % (reps, iters, len(fac["coe"]), os.cpu_count(), sum(len(p) for p in scans["points"]), t_build))
+                li_ba={"value": li_it / li_t, "unit": "iterations/s", "cores": 5, "calls": li_reps,
+                       "what": "LI_BA_Optimizer::damping_iter (voxel_map.hpp:624-713) on the same window, 9 IMU factors"},
+                stages_ms={"K1_insert_per_200k_scan": 1e3 * float(np.median(t_scan)), "K1_insert_full_window": 1e3 * t_ins,
+                           "K2_recut_extract_full_window": 1e3 * t_recut, "K5_margi_full_map": 1e3 * t_margi,
+                           "threads": "cut_voxel_multi phase 1 serial + 5 threads (VM:1964-2096), multi_recut / multi_margi 5 threads"},
+                rejected_steps=n_rej, iterations=iters,
+                sample="%d damping_iter calls (%d LM iterations, %d of them rejected steps that skip the Hessian pass as VM:443 does) on the full "
+                       "%d-voxel window, 5 worker threads of %d host cores; full-window rebuild (insert+recut, %d pts) took %.2f s"
+                       % (reps, iters, n_rej, len(fac["coe"]), os.cpu_count(), sum(len(p) for p in scans["points"]), t_build))
 
 
-def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16):
-    """The residual pass K4 on `copies` disjoint translated copies of the scene inserted through K1/K2 (V x copies)."""
-    import ctypes as C
+def alg_bytes_residual(V, occ):
+    """the residual pass reads (W_occ + 1) * 80 + 8 bytes and writes 176 bytes per planar voxel."""
+    return V * ((occ + 1) * 80 + 8 + 176)
+
+
+def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=56):
+    """The residual pass K4 on `copies` disjoint translated copies of the scene inserted through K1/K2 (V x copies): with 48
+    copies one pass touches > 2 x the 256 MiB Infinity Cache, so consecutive launches cannot be served from it."""
     W = wl.win_size
     ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
     R = poses0[:, :9].reshape(W, 3, 3)
     for i in range(W):
         pts = scans["points"][i]
-        tiles = [pts + (R[i].T @ np.array([100.0 * (c % 4), 100.0 * (c // 4), 0.0]))[None, :] for c in range(copies)]
+        tiles = [pts + (R[i].T @ np.array([100.0 * (c % 8), 100.0 * (c // 8), 0.0]))[None, :] for c in range(copies)]
         ctx.cut_voxel(i, np.concatenate(tiles), poses0[i])
+        del tiles
     ctx.recut(W, poses0, multi=False)
     V = ctx.size()
     occ = ctx.factor_occupancy()
@@ -111,10 +155,11 @@ def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16):
         ctx.evaluate_only_residual(poses0)
     t, n = ctx.timing_get("residual")
     us = max(t / max(n, 1) - ctx.timing_null_spans(32), 1e-3)
-    by = V * ((occ + 1) * 80 + W * 8 + 8 + 176)
+    by = alg_bytes_residual(V, occ)
     gbs = by / (us * 1e-6) / 1e9
     ctx.close()
-    return {"voxels": V, "occupied_frames_per_voxel": occ, "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch": by,
+    return {"copies": copies, "voxels": V, "occupied_frames_per_voxel": occ, "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch": by,
+            "layout_extra_bytes_per_launch": V * (W - occ) * 8, "exceeds_2x_infinity_cache": bool(by >= 2 * 256 * 2 ** 20),
             "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
 
 
@@ -182,7 +227,7 @@ def cold_residual_pass(ctx, torch, poses0, V, occ, W, reps=12):
     t, n = ctx.timing_get("residual")
     us = max(t / max(n, 1) - ctx.timing_null_spans(32), 1e-3)
     ctx.timing_enable(False); ctx.timing_select(None)
-    by = V * ((occ + 1) * 80 + W * 8 + 8 + 176)
+    by = alg_bytes_residual(V, occ)
     del scratch
     return {"avg_launch_us": us, "launches": n, "achieved": by / (us * 1e-6) / 1e9, "unit": "GB/s",
             "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "flush": "1 GiB device buffer rewritten before each launch"}
@@ -340,6 +385,54 @@ def odometry_update(capi, torch, wl, scans, reps=10, cpu=True):
     return res
 
 
+def load_profile(tag_glob="r02"):
+    """The committed rocprofv3 summary of this command (tools/prof_summary.py).  It is used ONLY when it was measured on the sources
+    this run executes (source hash of bench.py + library sources): a stale profile prices nothing."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from prof_summary import source_hash
+        cur = source_hash()
+    except Exception:
+        return None, "tools/prof_summary.py missing"
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k4_profile.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("source_hash") == cur:
+            best = (f, d)
+    if best is None:
+        return None, "no profile under profiles/ matches the running sources (hash %s): rocprofv3 fields are null, the live hipEvent figure prices the line" % cur[:12]
+    return best, None
+
+
+def launcher(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N rank processes (fresh children, spawned before this
+    process touches the GPU), one per device, and exit with their status."""
+    import socket
+    import subprocess
+    import torch
+    nd = torch.cuda.device_count()          # (does not initialise the GPU)
+    if nd < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d device(s); refusing to run fewer ranks than asked\n" % (args.gpus, nd))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        pr.wait()
+        rc = rc or pr.returncode
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,7 +441,11 @@ def main():
     ap.add_argument("--workload", default="hesai200k_w10")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaled", action="store_true")
+    ap.add_argument("--scene-copies", type=int, default=56)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launcher(args))
 
     import torch
     import torch.distributed as dist
@@ -358,18 +455,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("VBA_BENCH_ALLOW_MISMATCH"):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the line would report a GPU count that was not asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    local_rank = local_rank % torch.cuda.device_count()     # (rehearsals put several ranks on one card)
+    if os.environ.get("VBA_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d device(s) visible" % (world, torch.cuda.device_count()))
+    local_rank = local_rank % torch.cuda.device_count()     # (gloo rehearsals put several ranks on one card)
     torch.cuda.set_device(local_rank)
-    # VBA_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL all_reduce per LM iteration) with a single rank, to measure
-    # what the collective adds on a one-GPU box
+    # VBA_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL all-reduce per LM iteration) with a single rank, to measure
+    # what the exchange step adds on a one-GPU box
     dist_on = world > 1 or os.environ.get("VBA_BENCH_FORCE_DIST", "") not in ("", "0")
+    backend = os.environ.get("VBA_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only to rehearse several ranks on one card
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("VBA_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only to rehearse on one card
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -383,9 +484,11 @@ def main():
     opt.device = local_rank
     ctx = capi.Context(opt)
     if dist_on:
-        ctx.set_shard(rank, world)        # K1 keeps only the points whose root voxel falls in this rank's bucket range
-
-        ctx.set_torch_allreduce(torch, dist)   # collective issued on the context's stream (RCCL all_reduce, SUM)
+        if backend == "nccl":
+            ctx.rccl_init(dist, rank, world)   # the library's own RCCL communicator: ncclAllReduce on the context's stream, no Python in the loop
+        else:
+            ctx.set_shard(rank, world)         # K1 keeps only the points whose root voxel falls in this rank's bucket range
+            ctx.set_torch_allreduce(torch, dist)
 
     # full-window rebuild on the device (voxelslam.cpp:664-703): K1 insert of W scans, K2 recut + factor extraction.
     # The scans are uploaded to HBM once; the timed rebuild passes consume device pointers.
@@ -451,72 +554,96 @@ def main():
         dt = float(tt.item())
     t_res, n_res = ctx.timing_get("residual")
     null_us = ctx.timing_null_spans(64)      # what an event pair costs when it brackets nothing (subtracted below)
-    # second pass (not part of `value`): events around every kernel family
+    # second pass (not part of `value`): events around every kernel family; the trace tells how many steps were rejected ones
     ctx.timing_select(None)
     ctx.timing_reset()
     run_steps(min(args.steps, 90))
     torch.cuda.synchronize()
-
-    # per-kernel device time from hipEvents recorded on the launch stream inside the timed region
-    t_hes, n_hes = ctx.timing_get("hessian")
+    ctx.lm_begin(poses0, thd_num=2); ctx.lm_refresh_eigen()
+    for _ in range(3):
+        ctx.lm_iterate(sync=False)
+    ctx.lm_end(fetch=True)
+    tr = ctx.last_trace()
+    rejected_per_call = int((tr[:, 1] >= tr[:, 0]).sum()) if len(tr) else 0
+    # one full Hessian pass on its own (inside the loop a third of the launches are gated off, which would blur its duration)
+    t_hes_loop, n_hes_loop = ctx.timing_get("hessian")
     t_sol, n_sol = ctx.timing_get("solve")
+    t_red, n_red = ctx.timing_get("reduce")
+    ctx.timing_select("hessian"); ctx.timing_reset()
+    ctx.evaluate_only_residual(poses0)
+    for _ in range(20):
+        ctx.acc_evaluate2(poses0)
+    t_k3, n_k3 = ctx.timing_get("hessian")
+    k3_full_us = max(t_k3 / max(n_k3, 1) - null_us, 1e-3)
+    ctx.timing_select(None)
+
+    # per-kernel device time from hipEvents recorded on the launch stream
+    t_hes, n_hes = t_hes_loop, n_hes_loop
     V_local = ctx.size()
     occ = ctx.factor_occupancy()     # occupied (voxel, frame) slots per voxel
-    # algorithmic bytes per voxel: residual pass reads (W_occ+1)*80 + W*8 (the N column of every slot)
-    # + 8 (coe), writes 176; Hessian pass reads W_occ*80 + W*8 + 16*8 (eig 12, pcr N+v 4) + 8
-    bytes_res = V_local * ((occ + 1) * 80 + W * 8 + 8 + 176)
-    bytes_hes = V_local * (occ * 80 + W * 8 + 16 * 8 + 8)
+    # algorithmic bytes: residual pass reads (W_occ+1)*80 + 8, writes 176 per voxel; the SoA layout additionally
+    # reads the N of every EMPTY slot (8 B each) to find the occupied ones: reported separately as layout overhead.
+    # Hessian pass reads W_occ*80 + 80 + 96 + 8 per voxel (fixed cluster row is not read: it only needs pcr_add's N, v).
+    bytes_res = alg_bytes_residual(V_local, occ)
+    bytes_res_layout = V_local * (W - occ) * 8
+    bytes_hes = V_local * (occ * 80 + 80 + 96 + 8)
+    flops_hes = V_local * (occ * 600 + 2 * 3 * (6 * W) * (6 * W + 1) / 2.0)      # slot preparation + the G^T C G contraction
     res_us_raw = t_res / max(n_res, 1)
-    res_us = max(res_us_raw - null_us, 1e-3)     # launch duration = bracketed span - empty span (agrees with rocprofv3's average)
+    res_us = max(res_us_raw - null_us, 1e-3)     # launch duration = bracketed span - empty span
     hes_us = max(t_hes / max(n_hes, 1) - null_us, 1e-3)
-    dominant = "hessian" if t_hes >= t_res else "residual"
-    res_gbs = bytes_res / (res_us * 1e-6) / 1e9 if res_us > 0 else 0.0
-    hes_gbs = bytes_hes / (hes_us * 1e-6) / 1e9 if hes_us > 0 else 0.0
-    # HBM traffic of K4 from the PMC passes committed under profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # runs of this same command; gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE x2; 8-B-per-lane accesses are
-    # "uncalibrated" there, so this is an upper estimate)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")))
-        k4 = [v for k, v in pmc.items() if k.startswith("void vba::k_residual_w<10")][0]
-        if args.workload == "hesai200k_w10" and world == 1:
-            traffic = (2.0 * k4["FETCH_SIZE_KB_p75"] + k4["WRITE_SIZE_KB_p75"]) * 1024.0
-    except Exception:
-        pass
-    # the committed rocprofv3 summary of this same command (profiles/): average duration of the in-iteration launches.  It runs
-    # ~1.5 us above the event figure at this 10 us scale: the empty-span correction removes all of the marker cost, while
-    # part of it overlaps the kernel, and rocprofv3 counts the dispatch ramp inside the kernel
-    rocprof_us = None
-    try:
-        import csv
-        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_final_bench_kernel_stats.csv"))):
-            if row["Name"].startswith("void vba::k_residual_w<10, 1>"):     # the bench-size instantiation (<10, 3> is the scene x16 pass)
-                rocprof_us = float(row["AverageNs"]) / 1000.0
-                break
-    except Exception:
-        pass
-    # `achieved` / `frac` are priced at the LONGER of the two durations (the live hipEvent figure and, when the committed
-    # rocprofv3 summary of this command is present, its average for the kernel): the event figure is the optimistic one.
-    use_prof = bool(rocprof_us) and args.workload == "hesai200k_w10" and world == 1 and rocprof_us > res_us
-    dur_us = rocprof_us if use_prof else res_us
-    ach_gbs = bytes_res / (dur_us * 1e-6) / 1e9 if dur_us > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": "k_residual_w<10> (K4, evaluate_only_residual)", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "duration_basis": "rocprofv3 average (profiles/r01_final_bench_kernel_stats.csv), longer than the live hipEvent figure" if use_prof else "live hipEvent span minus empty span",
-            "frac_at_hipevent_duration": res_gbs / HBM_PEAK_GBS,
-            "avg_launch_us": res_us, "avg_span_us_raw": res_us_raw, "empty_span_us": null_us, "launches": n_res,
-            "rocprofv3_avg_launch_us": rocprof_us if (args.workload == "hesai200k_w10" and world == 1) else None,
-            "frac_at_rocprofv3_duration": (bytes_res / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (rocprof_us and args.workload == "hesai200k_w10" and world == 1) else None,
-            "algorithmic_bytes_per_launch": bytes_res,
-            "other_kernels": {"k_hessian2<10> (K3, acc_evaluate2; average incl. the launches gated off after a rejected step)": {"avg_launch_us": hes_us, "launches": n_hes, "algorithmic_GBps": hes_gbs,
-                                                                "algorithmic_bytes_per_launch": bytes_hes},
-                              "k_lm_solve (gauge + LDLT + retraction)": {"avg_launch_us": max(t_sol / max(n_sol, 1) - null_us, 1e-3), "launches": n_sol}},
-            "dominant_by_time": dominant}
+    sol_us = max(t_sol / max(n_sol, 1) - null_us, 1e-3)
+    red_us = max(t_red / max(n_red, 1) - null_us, 1e-3)
+    per_iter = {"hessian": t_hes / max(n_sol, 1), "reduce": t_red / max(n_sol, 1), "solve": t_sol / max(n_sol, 1), "residual": res_us}
+    dominant = max(per_iter, key=per_iter.get)
+    res_gbs = bytes_res / (res_us * 1e-6) / 1e9
 
-    # K4 on the same scene tiled 16x (the pass then exceeds the 256 MB Infinity Cache and fills the chip)
+    # rocprofv3 evidence of this same command, when (and only when) it was taken on the running sources
+    prof, prof_note = load_profile()
+    rocprof_us = traffic = None
+    prof_file = None
+    if prof is not None and args.workload == "hesai200k_w10" and world == 1:
+        prof_file, pd = prof
+        k4 = [k for k in pd["kernels"] if k["name"].startswith("vba::k_residual_s<%d" % W)]
+        if k4:
+            main_grid = max(k4, key=lambda k: k["launches"])           # the grid the LM loop launches (the side legs use other sizes)
+            rocprof_us = main_grid["avg_ns"] / 1000.0
+            if "FETCH_SIZE_KB_median" in main_grid and "WRITE_SIZE_KB_median" in main_grid:
+                # gfx950: FETCH_SIZE reports half of a coalesced stream's bytes (MI355X_MICROARCH.md "HBM"); 8-B-per-lane reads are
+                # uncalibrated there, so this is an upper estimate of the bytes that crossed the fabric (Infinity-Cache hits included)
+                traffic = (2.0 * main_grid["FETCH_SIZE_KB_median"] + main_grid["WRITE_SIZE_KB_median"]) * 1024.0
+    roof = {"bound": "hbm", "kernel": "k_residual_s<%d> (K4, evaluate_only_residual)" % W,
+            "achieved": res_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "duration_basis": "hipEvent pairs on the launch stream around every K4 launch of the timed region, minus the span of a pair that brackets nothing",
+            "avg_launch_us": res_us, "avg_span_us_raw": res_us_raw, "empty_span_us": null_us, "launches": n_res,
+            "algorithmic_bytes_per_launch": bytes_res, "algorithmic_bytes_per_voxel": bytes_res / max(V_local, 1),
+            "layout_extra_bytes_per_launch": bytes_res_layout,
+            "rocprofv3_avg_launch_us": rocprof_us,
+            "frac_at_rocprofv3_duration": (bytes_res / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
+            "rocprofv3_profile": os.path.relpath(prof_file, ROOT) if prof_file else None, "rocprofv3_note": prof_note,
+            "note": "V = %d voxels = %.1f MB per pass: the working set sits in the 256 MiB Infinity Cache between launches and one launch lasts a few "
+                    "microseconds, so this line is latency- rather than bandwidth-limited; roofline_residual_pass_big_scene is the same kernel on a "
+                    "pass that cannot be cached" % (V_local, bytes_res / 1e6),
+            "other_kernels": {
+                "k_hessian2<%d> (K3, acc_evaluate2)" % W: {"avg_launch_us": hes_us, "launches": n_hes, "note": "average incl. the launches gated off after a rejected step",
+                                                           "algorithmic_GBps": bytes_hes / (hes_us * 1e-6) / 1e9, "algorithmic_bytes_per_launch": bytes_hes,
+                                                           "flops_per_full_pass": flops_hes, "full_pass_us": k3_full_us,
+                                                           "fraction_of_fp64_peak": flops_hes / (k3_full_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS},
+                "k_reduce_partials": {"avg_launch_us": red_us, "launches": n_red},
+                "k_lm_solve_m (gauge + LDLT + retraction, one workgroup)": {"avg_launch_us": sol_us, "launches": n_sol}},
+            "per_iteration_us": per_iter, "dominant_by_time": dominant}
+
+    # K4 on the same scene tiled so that one pass touches more than twice the Infinity Cache
     scaled = None
     if world == 1 and not args.no_scaled:
-        scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=16)
+        scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=args.scene_copies)
+        if prof is not None:
+            k4 = [k for k in prof[1]["kernels"] if k["name"].startswith("vba::k_residual_s<%d" % W)]
+            if k4:
+                big = max(k4, key=lambda k: k["grid_threads"])
+                if big["grid_threads"] > 4 * 32 * W * (V_local // 32 + 1) // 4:
+                    scaled["rocprofv3_avg_launch_us"] = big["avg_ns"] / 1000.0
+                    if "FETCH_SIZE_KB_median" in big and "WRITE_SIZE_KB_median" in big:
+                        scaled["traffic"] = (2.0 * big["FETCH_SIZE_KB_median"] + big["WRITE_SIZE_KB_median"]) * 1024.0
 
     cold = lms = liv = hba = odo = None
     if world == 1 and not args.no_scaled:
@@ -535,9 +662,12 @@ def main():
             "config": {"workload": "%s: Hesai-32-like synthetic scans, %d pts/scan, W=%d, voxel %.2f m; %d planar voxels "
                                    "(%.1f occupied frames/voxel), lidar-only LM (Lidar_BA_Optimizer)"
                                    % (wl.name, wl.n_pts, W, wl.voxel_size, V_total, occ),
-                       "parallelism": "voxel-bucket shard x%d + all-reduce of [H|g|r]" % world if dist_on else "single GPU"},
+                       "parallelism": ("voxel-bucket shard x%d + RCCL all-reduce of [H|g|r] inside the library" % world) if (dist_on and backend == "nccl")
+                                      else ("voxel-bucket shard x%d + all-reduce hook (%s rehearsal)" % (world, backend)) if dist_on else "single GPU",
+                       "steps_note": "a step is one trip through the LM loop body VM:441-494; %d of the 3 steps of every damping_iter call are rejected "
+                                     "steps, which skip the Hessian pass exactly as VM:443 does (the CPU baseline runs the same sequence)" % rejected_per_call},
             "roofline": roof,
-            "roofline_residual_pass_scene_x16": scaled,
+            "roofline_residual_pass_big_scene": scaled,
             "local_mapping_step": lms,
             "li_ba_variant": liv,
             "hba_window": hba,
@@ -545,11 +675,15 @@ def main():
             "full_window_rebuild": {"points": n_points, "wall_ms": 1e3 * t_rebuild, "insert_device_ms": 1e-3 * t_ins / max(n_rebuild, 1),
                                     "recut_extract_device_ms": 1e-3 * t_rec / max(n_rebuild, 1),
                                     "insert_algorithmic_GBps": n_points * 24 / (t_ins / max(n_rebuild, 1) * 1e-6) / 1e9 if t_ins > 0 else None},
+            "k3_fraction_of_fp64_peak": flops_hes / (k3_full_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, scans, poses0)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if liv:
+                out["li_ba_gpu_over_cpu"] = liv["iterations_per_s"] / out["cpu_baseline"]["li_ba"]["value"]
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist_on:
         dist.destroy_process_group()
 

@@ -48,11 +48,19 @@ struct IMUST {  // tools.hpp:135-199: exactly the `state` layout of voxelba.h fo
 
 struct IMU_PRE {  // preintegration.hpp:11-331: exactly the `imu_pre` layout of voxelba.h
   double f[VBA_IMU_PRE_LEN];
-  IMU_PRE(const double *bg1 = nullptr, const double *ba1 = nullptr) {
+  double bg0[3] = {0, 0, 0}, ba0[3] = {0, 0, 0};
+  IMU_PRE(const double *bg1 = nullptr, const double *ba1 = nullptr) {   // IMU_PRE(bg, ba) PI:32-48
     std::memset(f, 0, sizeof(f));
     f[0] = f[4] = f[8] = 1.0;
-    if (bg1) std::memcpy(f + 15, bg1, 24);
-    if (ba1) std::memcpy(f + 18, ba1, 24);
+    if (bg1) { std::memcpy(f + 15, bg1, 24); std::memcpy(bg0, bg1, 24); }
+    if (ba1) { std::memcpy(f + 18, ba1, 24); std::memcpy(ba0, ba1, 24); }
+  }
+  // push_imu(deque<sensor_msgs::Imu::Ptr>&) PI:50-73 with the samples as arrays t[n], gyr[n][3], acc[n][3] and the noise globals
+  // noiseMeas / noiseWalk (PI:8) as diagonals
+  void push_imu(int n, const double *t, const double *gyr, const double *acc, const double *noise_meas6, const double *noise_walk6,
+                double scale_gravity = 1.0) {
+    const int st = vba_imu_preintegrate(n, t, gyr, acc, bg0, ba0, noise_meas6, noise_walk6, scale_gravity, f);
+    if (st != VBA_OK) throw std::runtime_error(std::string("libvoxelba: push_imu: ") + vba_status_string(st));
   }
 };
 
@@ -176,6 +184,16 @@ class VoxelMap {
   void cut_voxel(const PVec &pvec, int win_count, const IMUST &x, bool with_var = true) { insert(pvec, win_count, x, with_var, 0); }
   // cut_voxel_multi(...) VM:1964
   void cut_voxel_multi(const PVec &pvec, int win_count, const IMUST &x, bool with_var = true) { insert(pvec, win_count, x, with_var, 1); }
+  // pvec_update(pptr, x_curr, pwld) VH:242-265 + cut_voxel_multi VM:1964 fused on the device: pvec holds BODY-frame points and
+  // covariances (as var_init leaves them), x.cov the state covariance whose rotation / translation blocks inflate them
+  void pvec_update_cut_voxel_multi(const PVec &pvec, int win_count, const IMUST &x) {
+    const size_t n = pvec.size();
+    std::vector<double> p(n * 3), v(n * 9);
+    for (size_t i = 0; i < n; i++) { std::memcpy(&p[i * 3], pvec[i].pnt, 24); std::memcpy(&v[i * 9], pvec[i].var, 72); }
+    double pose[12];
+    std::memcpy(pose, x.R, 72); std::memcpy(pose + 9, x.p, 24);
+    check(c_, vba_map_pvec_update_cut_voxel(c_, win_count, (int)n, p.data(), v.data(), pose, x.cov, 1));
+  }
   // cut_voxel(feat_map, PVec&, wdsize, jour) VM:2108
   void cut_voxel_fix(const PVec &pvec, double jour) {
     std::vector<double> p(pvec.size() * 3);

@@ -236,5 +236,6 @@ def test_fullsize_rebuild_is_deterministic(capi, synth, scans):
     # (eigenvectors of near-isotropic non-planar leaves are ill-conditioned: eigenvalues and sums only)
     assert np.allclose(a[:, 10:13], b[:, 10:13], rtol=0, atol=1e-12 * max(1.0, np.abs(a[:, 22:28]).max() / 5))
     assert np.allclose(a[:, 22:32], b[:, 22:32], rtol=1e-11, atol=1e-13)
-    assert np.abs(hs[0][0] - hs[1][0]).max() < 1e-11 * np.abs(hs[0][0]).max()
+    # (H sums ~2e5 slot terms that each inherit the last-bit differences of the atomically accumulated cluster sums)
+    assert np.abs(hs[0][0] - hs[1][0]).max() < 1e-10 * np.abs(hs[0][0]).max()
     assert abs(hs[0][2] - hs[1][2]) < 1e-12 * abs(hs[0][2])

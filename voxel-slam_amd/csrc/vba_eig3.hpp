@@ -71,8 +71,11 @@ VBE_HD float eig_rcp_f32(float x) {
 
 // in: a00 a01 a02 a11 a12 a22 (the lower triangle, as Eigen reads it).  out: w0 <= w1 <= w2, V row-major with the eigenvectors in
 // its columns.  Returns false when the matrix needs the iterative solver (zero / non-finite / A = qI / a near-double pair).
-VBE_HD bool eig3_direct(double a00, double a01, double a02, double a11, double a12, double a22,
-                        double &w0, double &w1, double &w2, double *V) {
+struct Eig3 { double w0, w1, w2, v00, v01, v02, v10, v11, v12, v20, v21, v22; };   // V row-major: column c = eigenvector c
+
+// (results in a struct of scalars, not through a pointer to the caller's array: merged with the fallback's results they stay in
+//  registers, whereas stores through the shared pointer were turned into a run-time indexed private array, i.e. scratch memory)
+VBE_HD bool eig3_direct(double a00, double a01, double a02, double a11, double a12, double a22, Eig3 &o) {
   const double s = fmax(fmax(fmax(fabs(a00), fabs(a11)), fabs(a22)), fmax(fmax(fabs(a01), fabs(a02)), fabs(a12)));
   if (!(s > 1e-290 && s < 1e290)) return false;
   int e;
@@ -153,10 +156,19 @@ VBE_HD bool eig3_direct(double a00, double a01, double a02, double a11, double a
   // middle eigenvector
   const double mx = ay * bz - az * by, my = az * bx - ax * bz, mz = ax * by - ay * bx;
   const double un = ldexp(1.0, e);
-  w0 = (q + x0) * un; w1 = (q + x1) * un; w2 = (q + x2r) * un;
-  if (neg) { V[0] = ax; V[3] = ay; V[6] = az; V[2] = bx; V[5] = by; V[8] = bz; }
-  else { V[2] = ax; V[5] = ay; V[8] = az; V[0] = bx; V[3] = by; V[6] = bz; }
-  V[1] = mx; V[4] = my; V[7] = mz;
+  o.w0 = (q + x0) * un; o.w1 = (q + x1) * un; o.w2 = (q + x2r) * un;
+  o.v00 = neg ? ax : bx; o.v10 = neg ? ay : by; o.v20 = neg ? az : bz;
+  o.v02 = neg ? bx : ax; o.v12 = neg ? by : ay; o.v22 = neg ? bz : az;
+  o.v01 = mx; o.v11 = my; o.v21 = mz;
+  return true;
+}
+
+VBE_HD bool eig3_direct(double a00, double a01, double a02, double a11, double a12, double a22,
+                        double &w0, double &w1, double &w2, double *V) {
+  Eig3 o;
+  if (!eig3_direct(a00, a01, a02, a11, a12, a22, o)) return false;
+  w0 = o.w0; w1 = o.w1; w2 = o.w2;
+  V[0] = o.v00; V[1] = o.v01; V[2] = o.v02; V[3] = o.v10; V[4] = o.v11; V[5] = o.v12; V[6] = o.v20; V[7] = o.v21; V[8] = o.v22;
   return true;
 }
 

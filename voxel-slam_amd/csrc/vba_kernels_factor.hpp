@@ -64,69 +64,12 @@ __device__ __forceinline__ void jacobi_rot(double &app, double &aqq, double &apq
 
 #define VBA_SWAP(a, b) { double _t = a; a = b; b = _t; }
 
-// f32 rotation of the pre-pass below (same update as jacobi_rot, everything in f32: ~6 cycle dependent latency instead of ~40)
-__device__ __forceinline__ void jacobi_rot_f32(float &app, float &aqq, float &apq, float &arp, float &arq,
-                                               float &v0p, float &v0q, float &v1p, float &v1q, float &v2p, float &v2q) {
-  if (apq == 0.0f) return;
-  const float a = 0.5f * (aqq - app);
-  const float tf = apq * __builtin_amdgcn_rcpf(fabsf(a) + __builtin_amdgcn_sqrtf(a * a + apq * apq));
-  const float t = (a < 0.0f) ? -tf : tf;
-  const float c = __builtin_amdgcn_rsqf(1.0f + t * t), s = t * c;
-  const float cc = c * c, ss = s * s, cs = c * s;
-  const float npp = cc * app - 2.0f * cs * apq + ss * aqq, nqq = ss * app + 2.0f * cs * apq + cc * aqq;
-  app = npp; aqq = nqq; apq = 0.0f;
-  float x1 = arp, y1 = arq;
-  arp = c * x1 - s * y1; arq = s * x1 + c * y1;
-  x1 = v0p; y1 = v0q; v0p = c * x1 - s * y1; v0q = s * x1 + c * y1;
-  x1 = v1p; y1 = v1q; v1p = c * x1 - s * y1; v1q = s * x1 + c * y1;
-  x1 = v2p; y1 = v2q; v2p = c * x1 - s * y1; v2q = s * x1 + c * y1;
-}
-__device__ __forceinline__ double rsqrt_f64(double x) {
-  double c = __builtin_amdgcn_rsq(x);
-  c = c * (1.5 - 0.5 * x * c * c);
-  c = c * (1.5 - 0.5 * x * c * c);
-  return c;
-}
-
-// in: lower triangle a00,a10,a20,a11,a21,a22.  out: w0<=w1<=w2, V (row-major, columns = eigenvectors).
-// Two stages (the f64 sweeps are a chain of ~40-cycle dependent operations; five of them cost 9.2k cycles in K4):
-//   1. three Jacobi sweeps in f32 on the scaled matrix give eigenvectors V0 good to ~1e-7; V0 is re-orthonormalised in f64
-//      (Gram-Schmidt + cross product) and A' = V0^T A V0 is formed in f64 — an exact similarity with off-diagonals ~1e-7 |A|;
-//   2. the f64 sweeps start from (A', V0) and converge quadratically: two sweeps instead of five.
-// (kept out of line: it is the rare fallback of eig3_sym_dev below, and inlining it would charge its registers to every caller)
-struct Eig3Out { double w0, w1, w2, V[9]; };      // returned by value (registers): a pointer to the caller's V would put V into scratch
-__device__ __noinline__ Eig3Out eig3_jacobi_dev(double a00, double a01, double a02, double a11, double a12, double a22) {
+// in: lower triangle a00,a10,a20,a11,a21,a22.  out: w0<=w1<=w2, V (row-major, columns = eigenvectors).  Plain cyclic sweeps in f64:
+// this is the rare fallback of eig3_sym_dev below (near-double eigenvalue pairs, multiples of the identity, degenerate input),
+// so it is written for few registers, not for speed (the sweep loop is not unrolled).
+__device__ __forceinline__ Eig3 eig3_jacobi_dev(double a00, double a01, double a02, double a11, double a12, double a22) {
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
-  const double scale = fmax(fmax(fmax(fabs(a00), fabs(a11)), fabs(a22)), fmax(fmax(fabs(a01), fabs(a02)), fabs(a12)));
-  if (scale > 1e-290 && scale < 1e290 && (fabs(a01) + fabs(a02) + fabs(a12) != 0.0)) {
-    const double is = __builtin_amdgcn_rcp(scale);
-    float b00 = (float)(a00 * is), b01 = (float)(a01 * is), b02 = (float)(a02 * is), b11 = (float)(a11 * is), b12 = (float)(a12 * is), b22 = (float)(a22 * is);
-    float f00 = 1, f01 = 0, f02 = 0, f10 = 0, f11 = 1, f12 = 0, f20 = 0, f21 = 0, f22 = 1;
-#pragma unroll
-    for (int sweep = 0; sweep < 3; sweep++) {
-      jacobi_rot_f32(b00, b11, b01, b02, b12, f00, f01, f10, f11, f20, f21);
-      jacobi_rot_f32(b00, b22, b02, b01, b12, f00, f02, f10, f12, f20, f22);
-      jacobi_rot_f32(b11, b22, b12, b01, b02, f01, f02, f11, f12, f21, f22);
-    }
-    // columns of V0 -> orthonormal in f64
-    double x0 = f00, y0 = f10, z0 = f20, x1 = f01, y1 = f11, z1 = f21;
-    double r = rsqrt_f64(x0 * x0 + y0 * y0 + z0 * z0);
-    x0 *= r; y0 *= r; z0 *= r;
-    const double d = x1 * x0 + y1 * y0 + z1 * z0;
-    x1 -= d * x0; y1 -= d * y0; z1 -= d * z0;
-    r = rsqrt_f64(x1 * x1 + y1 * y1 + z1 * z1);
-    x1 *= r; y1 *= r; z1 *= r;
-    const double x2 = y0 * z1 - z0 * y1, y2 = z0 * x1 - x0 * z1, z2 = x0 * y1 - y0 * x1;
-    if (x0 == x0 && x1 == x1) {                   // (a NaN from a degenerate f32 pass falls back to the plain f64 sweeps)
-      // A v_j, then a'_ij = v_i . (A v_j)
-      const double p0 = a00 * x0 + a01 * y0 + a02 * z0, q0 = a01 * x0 + a11 * y0 + a12 * z0, s0 = a02 * x0 + a12 * y0 + a22 * z0;
-      const double p1 = a00 * x1 + a01 * y1 + a02 * z1, q1 = a01 * x1 + a11 * y1 + a12 * z1, s1 = a02 * x1 + a12 * y1 + a22 * z1;
-      const double p2 = a00 * x2 + a01 * y2 + a02 * z2, q2 = a01 * x2 + a11 * y2 + a12 * z2, s2 = a02 * x2 + a12 * y2 + a22 * z2;
-      a00 = x0 * p0 + y0 * q0 + z0 * s0; a01 = x0 * p1 + y0 * q1 + z0 * s1; a02 = x0 * p2 + y0 * q2 + z0 * s2;
-      a11 = x1 * p1 + y1 * q1 + z1 * s1; a12 = x1 * p2 + y1 * q2 + z1 * s2; a22 = x2 * p2 + y2 * q2 + z2 * s2;
-      v00 = x0; v10 = y0; v20 = z0; v01 = x1; v11 = y1; v21 = z1; v02 = x2; v12 = y2; v22 = z2;
-    }
-  }
+#pragma unroll 1
   for (int sweep = 0; sweep < 30; sweep++) {
     if (fabs(a01) + fabs(a02) + fabs(a12) == 0.0) break;
     jacobi_rot(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21, sweep);  // (p,q)=(0,1), r=2
@@ -136,9 +79,9 @@ __device__ __noinline__ Eig3Out eig3_jacobi_dev(double a00, double a01, double a
   if (a11 < a00) { VBA_SWAP(a00, a11); VBA_SWAP(v00, v01); VBA_SWAP(v10, v11); VBA_SWAP(v20, v21); }
   if (a22 < a00) { VBA_SWAP(a00, a22); VBA_SWAP(v00, v02); VBA_SWAP(v10, v12); VBA_SWAP(v20, v22); }
   if (a22 < a11) { VBA_SWAP(a11, a22); VBA_SWAP(v01, v02); VBA_SWAP(v11, v12); VBA_SWAP(v21, v22); }
-  Eig3Out o;
+  Eig3 o;
   o.w0 = a00; o.w1 = a11; o.w2 = a22;
-  o.V[0] = v00; o.V[1] = v01; o.V[2] = v02; o.V[3] = v10; o.V[4] = v11; o.V[5] = v12; o.V[6] = v20; o.V[7] = v21; o.V[8] = v22;
+  o.v00 = v00; o.v01 = v01; o.v02 = v02; o.v10 = v10; o.v11 = v11; o.v12 = v12; o.v20 = v20; o.v21 = v21; o.v22 = v22;
   return o;
 }
 
@@ -147,11 +90,10 @@ __device__ __noinline__ Eig3Out eig3_jacobi_dev(double a00, double a01, double a
 // non-finite input take the Jacobi sweeps above.
 __device__ __forceinline__ void eig3_sym_dev(double a00, double a01, double a02, double a11, double a12, double a22,
                                              double &w0, double &w1, double &w2, double *V) {
-  if (eig3_direct(a00, a01, a02, a11, a12, a22, w0, w1, w2, V)) return;
-  const Eig3Out o = eig3_jacobi_dev(a00, a01, a02, a11, a12, a22);
+  Eig3 o;
+  if (!eig3_direct(a00, a01, a02, a11, a12, a22, o)) o = eig3_jacobi_dev(a00, a01, a02, a11, a12, a22);
   w0 = o.w0; w1 = o.w1; w2 = o.w2;
-#pragma unroll
-  for (int k = 0; k < 9; k++) V[k] = o.V[k];
+  V[0] = o.v00; V[1] = o.v01; V[2] = o.v02; V[3] = o.v10; V[4] = o.v11; V[5] = o.v12; V[6] = o.v20; V[7] = o.v21; V[8] = o.v22;
 }
 
 // ------------------------------------------------------------------------------------------------
