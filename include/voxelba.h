@@ -293,6 +293,9 @@ int vba_set_shard(vba_ctx *ctx, int rank, int n_ranks);
  * Measurement hooks (bench.py): average device time in microseconds of the named kernel family since
  * the last reset, from hipEvents recorded on the context's stream around each launch.             */
 int vba_timing_enable(vba_ctx *ctx, int on);
+/* Measurement aid for the rocprofv3 PMC passes: one launch that reads exactly (n_bytes rounded down to 32 KiB) bytes with the
+ * factor store's access shape; its FETCH_SIZE calibrates the read-side counter correction (tools/prof_summary.py). */
+int vba_timing_calibration_read(vba_ctx *ctx, size_t n_bytes);
 /* Restrict the event bracketing to one kernel family (NULL / "" = all): two hipEventRecord calls per launch cost host
  * time, so the headline timed region brackets only the kernel whose roofline is reported. */
 int vba_timing_select(vba_ctx *ctx, const char *name);

@@ -126,3 +126,91 @@ def test_two_rank_hba_window_replicas_equal_single_rank(tmp_path):
     mp.spawn(_worker_hba, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     files = [p.name for p in tmp_path.iterdir()]
     assert "ok" in files, [(p.name, p.read_text()) for p in tmp_path.iterdir()]
+
+
+def _worker_rccl(out_dir):
+    """One rank, the library's OWN RCCL communicator (vba_rccl_init): the multi-rank LM flow — speculative Hessian pass, one
+    ncclAllReduce(ncclDouble, ncclSum) per iteration issued by the library on the context's stream — must reproduce the plain
+    single-GPU optimiser."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    os.environ["VBA_FORCE_COLLECTIVE"] = "1"           # take the exchange step although the communicator has one rank
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import synth, capi
+    wl = synth.CONFIGS["room20k_w4"]
+    s = synth.make_scans(wl)
+    W = wl.win_size
+    poses = synth.poses_flat(s["R0"], s["p0"])
+
+    def run(native):
+        ctx = capi.Context(capi.options_from_workload(wl))
+        if native:
+            uid = C.create_string_buffer(128)
+            ctx._chk(ctx.lib.vba_rccl_get_unique_id(uid))
+            ctx._chk(ctx.lib.vba_rccl_init(ctx.h, uid, C.c_int(0), C.c_int(1)))
+        for i in range(W):
+            ctx.cut_voxel(i, s["points"][i], poses[i], multi=True)
+        ctx.recut(W, poses, multi=True)
+        out = ctx.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
+        ctx.margi(W, out["poses"], jour=0.0)
+        leaves = ctx.dump_leaves()
+        ctx.close()
+        return out, leaves
+
+    a, la = run(True)
+    os.environ.pop("VBA_FORCE_COLLECTIVE")
+    b, lb = run(False)
+    ok = (np.abs(a["poses"] - b["poses"]).max() < 1e-9 and np.allclose(a["trace"], b["trace"], rtol=1e-8, atol=1e-12)
+          and np.abs(a["hess"] - b["hess"]).max() < 1e-9 * np.abs(b["hess"]).max() and la.shape == lb.shape)
+    open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write("poses %g trace %s vs %s" % (np.abs(a["poses"] - b["poses"]).max(), a["trace"].tolist(), b["trace"].tolist()))
+
+
+def test_native_rccl_exchange_step_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_worker_rccl, args=(str(tmp_path),))
+    p.start(); p.join(300)
+    assert p.exitcode == 0
+    files = [q.name for q in tmp_path.iterdir()]
+    assert "ok" in files, [(q.name, q.read_text()) for q in tmp_path.iterdir()]
+
+
+def _worker_hba_fail(rank, world, port, out_dir):
+    """A bottom-layer window that fails on ONE rank (too few voxels: its keyframes see nothing planar) must come back as the same
+    error on EVERY rank after the gather — nobody may be left waiting in a collective."""
+    import dataclasses
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import synth, capi
+    nk = 25
+    wk = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="hba_kf%d" % nk, win_size=nk, n_pts=6000)
+    sk = synth.make_scans(wk)
+    clouds = [p.astype(np.float32).astype(np.float64) for p in sk["points"]]
+    rng = np.random.default_rng(0)
+    for i in range(5, 15):                                    # window 1 (keyframes 5..14, owned by rank 1): isotropic noise, no planes
+        clouds[i] = rng.normal(0, 3.0, (400, 3)).astype(np.float32).astype(np.float64)
+    x0 = synth.poses_flat(sk["R0"], sk["p0"])
+    ctx = capi.Context(capi.options_from_workload(synth.CONFIGS["hesai200k_w10"], stream=torch.cuda.current_stream().cuda_stream))
+    ctx.set_shard(rank, world)
+    ctx.set_torch_allreduce(torch, dist)
+    status = 0
+    try:
+        ctx.hba_global(clouds, x0, x0, 2.0, 0.1, [0.25] * 4, 2)
+    except capi.VbaError as e:
+        status = e.status
+    open(os.path.join(out_dir, "rank%d" % rank), "w").write(str(status))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hba_failed_window_returns_on_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_hba_fail, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    st = sorted((p.name, p.read_text()) for p in tmp_path.iterdir())
+    assert len(st) == 2 and st[0][1] == st[1][1] and st[0][1] != "0", st

@@ -59,7 +59,10 @@ def main():
     for (name, grid), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         if not name.startswith("vba::"):
             continue
-        rec = {"name": name, "grid_threads": grid, "launches": len(v), "avg_ns": sum(v) / len(v), "median_ns": statistics.median(v),
+        med = statistics.median(v)
+        core = [x for x in v if x <= 3 * med]          # without the cache-flushed launches of bench.py's `roofline.cold` leg (same grid, ~30x longer)
+        rec = {"name": name, "grid_threads": grid, "launches": len(v), "avg_ns": sum(v) / len(v), "median_ns": med,
+               "avg_ns_without_outliers": sum(core) / len(core), "outliers_gt_3x_median": len(v) - len(core),
                "min_ns": min(v), "max_ns": max(v), "total_ns": sum(v)}
         for which in pmc:
             vals = pmc[which].get((name, grid))
@@ -67,6 +70,11 @@ def main():
                 rec[which + "_KB_median"] = statistics.median(vals)
                 rec[which + "_launches"] = len(vals)
         out["kernels"].append(rec)
+    # read-side calibration: k_calib_read8 reads exactly grid_threads * 128 bytes (vba_timing_calibration_read)
+    for k in out["kernels"]:
+        if k["name"].startswith("vba::k_calib_read8") and k.get("FETCH_SIZE_KB_median"):
+            out["calibration"] = {"known_read_bytes": k["grid_threads"] * 128, "FETCH_SIZE_KB": k["FETCH_SIZE_KB_median"],
+                                  "fetch_bytes_per_counted_byte": k["grid_threads"] * 128 / (k["FETCH_SIZE_KB_median"] * 1024.0)}
     path = os.path.join(ROOT, "profiles", "%s_k4_profile.json" % tag)
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path, "with", len(out["kernels"]), "(kernel, grid) groups; source hash", out["source_hash"][:12])

@@ -149,6 +149,17 @@ __global__ void k_count_slots(FactorView f, int n, unsigned long long *out) {
   if (c) atomicAdd(out, c);
 }
 
+// Calibration of rocprofv3's FETCH_SIZE for this library's access shape (MI355X_MICROARCH.md, "HBM": the counter is exact x1/2 for
+// 16-byte-per-lane streams and uncalibrated for others): every thread reads 16 doubles, 8 bytes per lane, 512 contiguous bytes
+// per wave instruction — what the SoA factor store is read with — so the launch reads exactly gridDim * blockDim * 128 bytes.
+__global__ __launch_bounds__(256) void k_calib_read8(const double *__restrict__ buf, double *__restrict__ sink) {
+  const size_t nthr = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc += buf[t + (size_t)k * nthr];
+  if (acc == 123.456) sink[0] = acc;     // (never true for the zero-filled buffer: keeps the loads alive)
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: residual pass  <->  LidarFactor::evaluate_only_residual voxel_map.hpp:285-325 (+ PointCluster::transform tools.hpp:357-363).
 // Algorithmic traffic per voxel: read (W_occ + 1) * 80 + 8 B, write 176 B.
@@ -186,6 +197,13 @@ __device__ __forceinline__ double dpp_mov_f64(double x, double old, const int ct
   }
   (void)row_mask;
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over each aligned group of 8 lanes, result in all 8 lanes (fixed tree)
+__device__ __forceinline__ double group8_sum(double x) {
+  x += dpp_mov_f64(x, x, 0xB1, 0xF);      // quad_perm [1,0,3,2]
+  x += dpp_mov_f64(x, x, 0x4E, 0xF);      // quad_perm [2,3,0,1]
+  x += dpp_mov_f64(x, x, 0x141, 0xF);     // row_half_mirror
+  return x;
 }
 __device__ __forceinline__ double wave_sum_to_lane63(double x) {
   x += dpp_mov_f64(x, x, 0xB1, 0xF);      // quad_perm [1,0,3,2]
@@ -381,7 +399,7 @@ __global__ __launch_bounds__(256) void k_sum_scalar(const double *__restrict__ p
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int hess2_tv(int W) {   // voxels per tile: ~256 / W slot threads = exactly 4 waves, multiple of 8, K-split divisible
-  return W == 2 ? 128 : W == 3 ? 80 : W == 4 ? 64 : W == 5 ? 48 : W == 6 ? 40 : W == 8 ? 32 : W == 10 ? 24 : 16;
+  return W == 2 ? 128 : W == 3 ? 80 : W == 4 ? 64 : W == 5 ? 48 : W == 6 ? 40 : (W == 7 || W == 8) ? 32 : (W == 9 || W == 10) ? 24 : 16;
 }
 constexpr int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
 
@@ -655,15 +673,13 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
       }
     }
   }
-  // E / gradient / residual: 8-lane groups never straddle a frame (TV % 8 == 0)
+  // E / gradient / residual: 8-lane groups never straddle a frame (TV % 8 == 0).  Data-parallel-primitive adds: the same 28 x 3
+  // steps through __shfl_xor (ds_bpermute, ~100 cycles of LDS round trip per dependent step) took most of the 7.7 us epilogue.
 #pragma unroll
-  for (int m = 4; m >= 1; m >>= 1) {
+  for (int k = 0; k < 6; k++) { Err[k] = group8_sum(Err[k]); Ett[k] = group8_sum(Ett[k]); gj[k] = group8_sum(gj[k]); }
 #pragma unroll
-    for (int k = 0; k < 6; k++) { Err[k] += __shfl_xor(Err[k], m, 64); Ett[k] += __shfl_xor(Ett[k], m, 64); gj[k] += __shfl_xor(gj[k], m, 64); }
-#pragma unroll
-    for (int k = 0; k < 9; k++) Ert[k] += __shfl_xor(Ert[k], m, 64);
-    rres += __shfl_xor(rres, m, 64);
-  }
+  for (int k = 0; k < 9; k++) Ert[k] = group8_sum(Ert[k]);
+  rres = group8_sum(rres);
   if ((tid & 7) == 0) {
     const int g8 = tid >> 3;
 #pragma unroll

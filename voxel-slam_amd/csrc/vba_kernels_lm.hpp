@@ -36,243 +36,12 @@ __device__ __forceinline__ void so3_exp_dev(const double *w, double *R) {   // t
 // `red` = the reduced [H | g | r] of the last Hessian pass.  It is never modified here: the gauge (first 6 rows/cols ->
 // identity, JacT.head(6) = 0, VM:452-455) and the damping u*diag are applied while the system is loaded, so a rejected
 // step re-reads the same H with a new u (VM:443) and `red[0..n^2)` doubles as *hess (VM:446).  With more than one rank
-// the hook all-reduces `red` in place on every iteration, so the valid copy is kept in `raw` (copy_raw != 0).
-//
-// Fast path, n = 6W <= 64: one wave owns the factorisation, lane i owns row i of P(H+uD)P^T.
-//   * [H|g|r] is staged into LDS once (256 threads), permuted/gauged/damped into the lane-strided image Lr[j][lane];
-//   * the factorisation is BLOCKED by pose (6 columns): the panel update is 6 independent dot products over the finished
-//     columns (one own-row read reused 6x, T read as three b128 from the transposed image TsT[j][k]), the 6x6 diagonal
-//     block is eliminated in registers with v_readlane broadcasts — no LDS round trip sits on the dependent chain;
-//   * all loops stay rolled (a fully unrolled register-resident variant was instruction-fetch bound: 40 us per launch).
+// the exchange step all-reduces `red` in place on every iteration, so the valid copy is kept in `raw` (copy_raw != 0).
 // Elimination order = Eigen's LDLT pivoting: largest |diagonal| of the *stored* matrix first (ldlt_inplace::unblocked),
-// realised as a rank computation (first index wins ties).  Measured ablation of the earlier unblocked LDS version:
-// factorisation 36 us, substitutions 5 us, prologue+epilogue 10 us of a 58 us launch (profiles/r01_solve_ablation.txt).
-template <int W>
-__global__ __launch_bounds__(256) void k_lm_solve_w(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw) {
-  constexpr int n = 6 * W;
-  static_assert(n <= 64, "single-wave solve");
-  __shared__ __attribute__((aligned(16))) double TsT[n][n + 2];   // TsT[j][k] = T[k][j] = d_j L[k][j]
-  __shared__ double Lr[n][64];                                   // Lr[j][lane] = L[lane][j]
-  __shared__ double Ls[n][n + 1];                                // Ls[k][i] = L[k][i]
-  __shared__ double dsh[n], gsh[n], hd[n], dxs[n];
-  __shared__ int ord[n];
-  using C2 = HessCfg2<W>;
-  const int tid = threadIdx.x;
-  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
-  const double u = s->u;
-  if (stop || (dbg & 8)) return;
-  const double *__restrict__ src = (copy_raw && !calc) ? raw : red;       // tile layout (vba_kernels_factor.hpp)
-  if (copy_raw && calc)
-    for (int t = tid; t < C2::NOUT2; t += 256) raw[t] = src[t];
-  double xr[12];                           // this lane's pose (retraction input), fetched while the factorisation runs
-  if (tid < W)
-#pragma unroll
-    for (int k = 0; k < 12; k++) xr[k] = s->x[12 * tid + k];
-  if (tid == 0 && calc) { const double r = src[C2::RB]; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
-  if (tid < n) {
-    const double h = tid < 6 ? 1.0 : tl_fetch<W>(src, tid, tid);                                          // gauge VM:452-455
-    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : src[C2::GB + tid];
-    dsh[tid] = fabs(h + u * h);
-  }
-  __syncthreads();
-  if (tid < n) {
-    const double me = dsh[tid];
-    int rank = 0;
-#pragma unroll 12
-    for (int j = 0; j < n; j++) { const double o = dsh[j]; rank += (o > me || (o == me && j < tid)) ? 1 : 0; }
-    ord[rank] = tid;
-  }
-  __syncthreads();
-  for (int t = tid; t < n * 64; t += 256) {            // B = P (Hess + u D) P^T, lower part, lane-strided, gathered from HBM/L2
-    const int j = t >> 6, i = t & 63;
-    double a = 0.0;
-    if (i < n && j <= i) {
-      const int pi = ord[i], pj = ord[j];
-      a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : tl_fetch<W>(src, pi, pj);
-      if (i == j) a += u * a;
-    }
-    Lr[j][i] = a;
-  }
-  __syncthreads();
-  if (tid >= 64 || (dbg & 4)) return;
-  const bool stamp = (dbg & 16) && tid == 0;
-  if (stamp) { s->stamps[0] = wall_clock64(); s->stamps[50] = clock64(); }
-
-  for (int b = 0; b < ((dbg & 1) ? 0 : W); b++) {
-    const int k0 = 6 * b;
-    double sc[6], lc[6], tc[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) sc[c] = Lr[k0 + c][tid];
-    // (1) panel update with the finished columns j < k0 (k0 is a multiple of 6: the unrolled body has no remainder)
-    for (int jb = 0; jb < b; jb++) {
-#pragma unroll
-      for (int jj = 0; jj < 6; jj++) {
-        const int j = 6 * jb + jj;
-        const double lj = Lr[j][tid];
-        const double2 t0 = *reinterpret_cast<const double2 *>(&TsT[j][k0]);
-        const double2 t1 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 2]);
-        const double2 t2 = *reinterpret_cast<const double2 *>(&TsT[j][k0 + 4]);
-        sc[0] -= lj * t0.x; sc[1] -= lj * t0.y; sc[2] -= lj * t1.x; sc[3] -= lj * t1.y; sc[4] -= lj * t2.x; sc[5] -= lj * t2.y;
-      }
-    }
-    if (stamp) s->stamps[1 + 3 * b] = clock64();
-    // (2) the 6x6 diagonal block, in registers
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const int k = k0 + c;
-#pragma unroll
-      for (int c2 = 0; c2 < c; c2++) sc[c] -= lc[c2] * readlane_f64(tc[c2], k);     // T[k][k0+c2] lives in lane k
-      const double dk = readlane_f64(sc[c], k);
-      // 1/dk by v_rcp_f64 + two Newton steps (the dependent chain of the factorisation runs through this pivot)
-      double inv = __builtin_amdgcn_rcp(dk);
-      inv = fma(fma(-dk, inv, 1.0), inv, inv);
-      inv = fma(fma(-dk, inv, 1.0), inv, inv);
-      const double l = (fabs(dk) > 0.0) ? sc[c] * inv : sc[c];
-      lc[c] = l; tc[c] = l * dk;
-      if (tid == k) dsh[k] = dk;
-    }
-    if (stamp) s->stamps[2 + 3 * b] = clock64();
-    // (3) publish the block's columns
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const int k = k0 + c;
-      if (tid > k && tid < n) { Lr[k][tid] = lc[c]; TsT[k][tid] = tc[c]; Ls[tid][k] = lc[c]; }
-    }
-    __syncthreads();
-    if (stamp) s->stamps[3 + 3 * b] = clock64();
-  }
-  // solve  P^T L^-T D^-1 L^-1 P (-g)
-  double y = tid < n ? -gsh[ord[tid]] : 0.0;
-#pragma unroll 12
-  for (int j = 0; j < ((dbg & 2) ? 0 : n); j++) {
-    const double lij = Lr[j][tid];
-    const double yj = readlane_f64(y, j);
-    if (tid > j && tid < n) y -= lij * yj;
-  }
-  {
-    const double dd = tid < n ? dsh[tid] : 1.0;
-    y = (fabs(dd) > 2.2250738585072014e-308) ? y / dd : 0.0;
-  }
-#pragma unroll 12
-  for (int j = ((dbg & 2) ? -1 : n - 1); j >= 0; j--) {
-    const double lji = tid < n ? Ls[j][tid] : 0.0;
-    const double yj = readlane_f64(y, j);
-    if (tid < j) y -= lji * yj;
-  }
-  if (tid < n) dxs[ord[tid]] = y;
-  __syncthreads();
-  if (stamp) { s->stamps[40] = wall_clock64(); s->stamps[51] = clock64(); }
-  if (tid < W) {                                                                                        // VM:460-464
-    double E[9];
-    so3_exp_dev(dxs + 6 * tid, E);
-    const double *R = xr;
-    double *Rt = s->xt + 12 * tid;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * E[c] + R[3 * r + 1] * E[3 + c] + R[3 * r + 2] * E[6 + c];
-#pragma unroll
-    for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dxs[6 * tid + 3 + k];
-  }
-  double q = tid < n ? dxs[tid] * (u * hd[tid] * dxs[tid] - gsh[tid]) : 0.0;                              // VM:465
-  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-  if (tid == 0) s->q1 = 0.5 * q;
-}
-
-// Generic path (n = 6W up to 96, i.e. W = 12, 16): rows in LDS, one row per thread, two barriers per elimination step.
-template <int W>
-__global__ __launch_bounds__(128) void k_lm_solve_g(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (s->stop) return;
-  using C2 = HessCfg2<W>;
-  constexpr int n = 6 * W, ld = n + 2;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  double *L = lds, *T = L + (size_t)n * ld, *d = T + (size_t)n * ld, *y = d + n, *dx = y + n, *hd = dx + n, *gsh = hd + n;
-  int *ord = (int *)(gsh + n);
-  const int calc = s->is_calc_hess;
-  if (copy_raw && calc)
-    for (int t = tid; t < C2::NOUT2; t += nt) raw[t] = red[t];
-  __syncthreads();
-  const double *__restrict__ H = copy_raw ? raw : red;      // tile layout
-  if (tid == 0 && calc) { const double r = H[C2::RB]; s->r1 = r; if (s->iter == 0) s->resis_first = r; }
-  const double u = s->u;
-  if (tid < n) {
-    const double h = tid < 6 ? 1.0 : tl_fetch<W>(H, tid, tid);
-    hd[tid] = h; gsh[tid] = tid < 6 ? 0.0 : H[C2::GB + tid];
-    d[tid] = fabs(h + u * h);
-  }
-  __syncthreads();
-  if (tid < n) {
-    const double me = d[tid];
-    int rank = 0;
-    for (int j = 0; j < n; j++) { const double o = d[j]; rank += (o > me || (o == me && j < tid)) ? 1 : 0; }
-    ord[rank] = tid;
-  }
-  __syncthreads();
-  for (int t = tid; t < n * n; t += nt) {
-    const int i = t / n, j = t % n;
-    if (j <= i) {
-      const int pi = ord[i], pj = ord[j];
-      double a = (pi < 6 || pj < 6) ? ((pi == pj) ? 1.0 : 0.0) : tl_fetch<W>(H, pi, pj);
-      if (i == j) a += u * a;
-      L[i * ld + j] = a;
-    }
-  }
-  __syncthreads();
-  for (int k = 0; k < n; k++) {
-    double sacc = 0.0;
-    if (tid >= k && tid < n) {
-      sacc = L[tid * ld + k];
-      const double *li = L + (size_t)tid * ld, *tk = T + (size_t)k * ld;
-      int j = 0;
-      for (; j + 1 < k; j += 2) {
-        const double2 a = *reinterpret_cast<const double2 *>(li + j), b = *reinterpret_cast<const double2 *>(tk + j);
-        sacc -= a.x * b.x; sacc -= a.y * b.y;
-      }
-      if (j < k) sacc -= li[j] * tk[j];
-      if (tid == k) d[k] = sacc;
-    }
-    __syncthreads();
-    if (tid > k && tid < n) {
-      const double dk = d[k];
-      const double l = (fabs(dk) > 0.0) ? sacc / dk : sacc;
-      L[tid * ld + k] = l;
-      T[tid * ld + k] = l * dk;
-    }
-    __syncthreads();
-  }
-  if (tid < n) y[tid] = -gsh[ord[tid]];
-  __syncthreads();
-  for (int j = 0; j < n; j++) {
-    if (tid > j && tid < n) y[tid] -= L[tid * ld + j] * y[j];
-    __syncthreads();
-  }
-  if (tid < n) { const double dd = d[tid]; y[tid] = (fabs(dd) > 2.2250738585072014e-308) ? y[tid] / dd : 0.0; }
-  __syncthreads();
-  for (int j = n - 1; j >= 0; j--) {
-    if (tid < j) y[tid] -= L[j * ld + tid] * y[j];
-    __syncthreads();
-  }
-  if (tid < n) dx[ord[tid]] = y[tid];
-  __syncthreads();
-  if (tid < W) {
-    double E[9];
-    so3_exp_dev(dx + 6 * tid, E);
-    const double *R = s->x + 12 * tid;
-    double *Rt = s->xt + 12 * tid;
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * E[c] + R[3 * r + 1] * E[3 + c] + R[3 * r + 2] * E[6 + c];
-    for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dx[6 * tid + 3 + k];
-  }
-  if (tid < n) y[tid] = dx[tid] * (u * hd[tid] * dx[tid] - gsh[tid]);
-  __syncthreads();
-  if (tid == 0) {
-    double q = 0.0;
-    for (int j = 0; j < n; j++) q += y[j];
-    s->q1 = 0.5 * q;
-  }
-}
-
+// realised as a rank computation (first index wins ties).
+// (History, measured on MI355X at n = 60: unblocked LDS rows 58 us -> one wave blocked by pose 30.8 us -> this kernel 24 us,
+//  profiles/r01_solve_ablation.txt; the two earlier kernels are no longer part of the library.)
+//
 // Blocked variant (vba_ldlt.hpp) for every supported window (n = 6W <= 96): trailing matrix in MFMA accumulators, panels
 // of 8 columns, two barriers per panel.  Everything the kernel reads was written by other kernels (in general on another
 // XCD, ~2 us per dependent trip), so the whole reduced system is requested up front and staged in LDS before the first branch.

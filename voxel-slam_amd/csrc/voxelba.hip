@@ -227,15 +227,10 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
 
 int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0) {
   switch (c->opt.win_size) {
-    case 2: return launch_hessian2_t<2>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 3: return launch_hessian2_t<3>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 4: return launch_hessian2_t<4>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 5: return launch_hessian2_t<5>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 6: return launch_hessian2_t<6>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 8: return launch_hessian2_t<8>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 10: return launch_hessian2_t<10>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 12: return launch_hessian2_t<12>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
-    case 16: return launch_hessian2_t<16>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+#define VBA_H_CASE(WW) case WW: return launch_hessian2_t<WW>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+    VBA_H_CASE(2) VBA_H_CASE(3) VBA_H_CASE(4) VBA_H_CASE(5) VBA_H_CASE(6) VBA_H_CASE(7) VBA_H_CASE(8) VBA_H_CASE(9) VBA_H_CASE(10)
+    VBA_H_CASE(11) VBA_H_CASE(12) VBA_H_CASE(13) VBA_H_CASE(14) VBA_H_CASE(15) VBA_H_CASE(16)
+#undef VBA_H_CASE
     default: return VBA_ERR_UNSUPPORTED_WINDOW;
   }
 }
@@ -357,7 +352,8 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
 int tiles_to_full(vba_ctx *c, const double *src) {
 #define VBA_TF_CASE(WW) case WW: hipLaunchKernelGGL(k_tiles_to_full<WW>, dim3(16), dim3(256), 0, c->stream, src, c->d_full); break;
   switch (c->opt.win_size) {
-    VBA_TF_CASE(2) VBA_TF_CASE(3) VBA_TF_CASE(4) VBA_TF_CASE(5) VBA_TF_CASE(6) VBA_TF_CASE(8) VBA_TF_CASE(10) VBA_TF_CASE(12) VBA_TF_CASE(16)
+    VBA_TF_CASE(2) VBA_TF_CASE(3) VBA_TF_CASE(4) VBA_TF_CASE(5) VBA_TF_CASE(6) VBA_TF_CASE(7) VBA_TF_CASE(8) VBA_TF_CASE(9) VBA_TF_CASE(10)
+    VBA_TF_CASE(11) VBA_TF_CASE(12) VBA_TF_CASE(13) VBA_TF_CASE(14) VBA_TF_CASE(15) VBA_TF_CASE(16)
     default: return VBA_ERR_UNSUPPORTED_WINDOW;
   }
 #undef VBA_TF_CASE
@@ -460,12 +456,6 @@ int vba_create(const vba_options *opt, vba_ctx **out) {
   if (ensure_partial(c, (size_t)kMaxBlocksHess * (nout_tl(W) > nout ? nout_tl(W) : nout)) != VBA_OK || ensure_pin(c, 65536 + (size_t)nout + 1024) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
   if (hipMalloc((void **)&c->d_lm, sizeof(LmDev)) != hipSuccess || hipMalloc((void **)&c->d_raw, ((size_t)nout_tl(W) + 64) * 8) != hipSuccess ||
       hipHostMalloc((void **)&c->h_lm, sizeof(LmDev), hipHostMallocDefault) != hipSuccess) { vba_destroy(c); return VBA_ERR_HIP; }
-  {
-    const int n = 6 * W, ld = n + 2;
-    const int lds = (int)(((size_t)2 * n * ld + 5 * n) * 8 + (size_t)n * 4 + 64);
-    hipFuncSetAttribute((const void *)k_lm_solve_g<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute((const void *)k_lm_solve_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
   if (opt->max_voxels && factor_reserve(c, (int)opt->max_voxels) != VBA_OK) { vba_destroy(c); return VBA_ERR_HIP; }
   map_init(c->map, c->opt);
   *out = c;
@@ -678,33 +668,12 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   if (st) return st;
   TimedSpan sp{};
   span_begin(c, "solve", sp);
-  static const bool old_solve = getenv("VBA_SOLVE_OLD") != nullptr;     // diagnostic: the single-wave / unblocked kernels
-  bool launched = false;
-  if (!old_solve) {
-    launched = true;
-    switch (W) {
-#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-      VBA_SM_CASE(2) VBA_SM_CASE(3) VBA_SM_CASE(4) VBA_SM_CASE(5) VBA_SM_CASE(6) VBA_SM_CASE(8) VBA_SM_CASE(10) VBA_SM_CASE(12) VBA_SM_CASE(16)
-#undef VBA_SM_CASE
-      default: launched = false;
-    }
-  }
-  if (!launched)
   switch (W) {
-    case 2: hipLaunchKernelGGL(k_lm_solve_w<2>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    case 3: hipLaunchKernelGGL(k_lm_solve_w<3>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    case 4: hipLaunchKernelGGL(k_lm_solve_w<4>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    case 5: hipLaunchKernelGGL(k_lm_solve_w<5>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    case 6: hipLaunchKernelGGL(k_lm_solve_w<6>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    case 8: hipLaunchKernelGGL(k_lm_solve_w<8>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    case 10: hipLaunchKernelGGL(k_lm_solve_w<10>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
-    default: {
-      const int n = 6 * W, ld = n + 2;
-      const size_t lds = ((size_t)2 * n * ld + 5 * n) * 8 + (size_t)n * 4 + 64;
-      if (W == 12) hipLaunchKernelGGL(k_lm_solve_g<12>, dim3(1), dim3(128), lds, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw);
-      else if (W == 16) hipLaunchKernelGGL(k_lm_solve_g<16>, dim3(1), dim3(128), lds, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw);
-      else return VBA_ERR_UNSUPPORTED_WINDOW;
-    }
+#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+    VBA_SM_CASE(2) VBA_SM_CASE(3) VBA_SM_CASE(4) VBA_SM_CASE(5) VBA_SM_CASE(6) VBA_SM_CASE(7) VBA_SM_CASE(8) VBA_SM_CASE(9) VBA_SM_CASE(10)
+    VBA_SM_CASE(11) VBA_SM_CASE(12) VBA_SM_CASE(13) VBA_SM_CASE(14) VBA_SM_CASE(15) VBA_SM_CASE(16)
+#undef VBA_SM_CASE
+    default: return VBA_ERR_UNSUPPORTED_WINDOW;
   }
   span_end(c, "solve", sp);
   double *d_r = c->d_scal;
@@ -764,16 +733,11 @@ int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
   if (hess) std::memcpy(hess, c->h_pin + 32768, (size_t)n * n * sizeof(double));
   if (resis2) { resis2[0] = h->resis_first; resis2[1] = h->r2; }
   c->trace.assign(h->trace, h->trace + 5 * h->n_trace);
-  if ((h->pad & 16) && !getenv("VBA_SOLVE_OLD")) {
+  if (h->pad & 16) {
     fprintf(stderr, "[k_lm_solve_m cycles] prologue %lld | tile load %lld | factorisation %lld | backsub %lld | epilogue %lld | panels:", h->stamps[1] - h->stamps[0],
             h->stamps[2] - h->stamps[1], h->stamps[3] - h->stamps[2], h->stamps[4] - h->stamps[3], h->stamps[5] - h->stamps[4]);
     for (int kb = 0; kb < 8; kb++) fprintf(stderr, " %lld+%lld", h->stamps[9 + 2 * kb] - h->stamps[8 + 2 * kb], kb < 7 ? h->stamps[10 + 2 * kb] - h->stamps[9 + 2 * kb] : 0LL);
     fprintf(stderr, "\n");
-  } else if (h->pad & 16) {
-    fprintf(stderr, "[solve stamps, shader cycles rel. to factorisation start]");
-    for (int i = 1; i <= 30; i++) fprintf(stderr, " %lld", h->stamps[i] - h->stamps[50]);
-    fprintf(stderr, " | subst end %lld | shader clock %.0f MHz\n", h->stamps[40] - h->stamps[0],
-            100.0 * (double)(h->stamps[51] - h->stamps[50]) / (double)(h->stamps[40] - h->stamps[0]));
   }
   c->lm.active = false;
   return VBA_OK;
@@ -1678,6 +1642,21 @@ int vba_set_shard(vba_ctx *c, int rank, int n_ranks) {
 }
 
 // ---------------------------------------------------------------- timing
+// Measurement aid: one launch that reads exactly n_bytes (rounded down to a multiple of 32 KiB) from a zero-filled scratch buffer
+// in the access shape of the factor store (k_calib_read8).  Under `rocprofv3 --pmc FETCH_SIZE` its counter value calibrates the
+// read-side correction factor tools/prof_summary.py applies to the residual pass.
+int vba_timing_calibration_read(vba_ctx *c, size_t n_bytes) {
+  const size_t nblk = n_bytes / (256 * 128);
+  if (nblk == 0 || nblk > 0x7fffffffu) return VBA_ERR_BAD_ARG;
+  double *buf = nullptr;
+  HIPCHK(c, hipMalloc((void **)&buf, nblk * 256 * 128 + 64));
+  HIPCHK(c, hipMemsetAsync(buf, 0, nblk * 256 * 128 + 64, c->stream));
+  hipLaunchKernelGGL(k_calib_read8, dim3((unsigned)nblk), dim3(256), 0, c->stream, buf, buf + nblk * 256 * 16);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(buf);
+  return VBA_OK;
+}
 int vba_timing_enable(vba_ctx *c, int on) { c->timing = on != 0; return VBA_OK; }
 int vba_timing_null_span(vba_ctx *c) {   // an event pair around nothing: the bracketing overhead itself (recorded as "null")
   TimedSpan s{};
