@@ -1,0 +1,38 @@
+"""The large-store form of the residual pass (two kernels beyond 2^17 voxels, see k_residual_s<..., SPLIT> / k_residual_eig): the same
+factors pushed 8x over must give 8x the residual and, voxel for voxel, the eigen-pairs and sums of the single-kernel pass."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split_residual_pass_equals_fused(oracle):
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    wl = synth.CONFIGS["hesai200k_w10"]
+    s = synth.make_scans(wl)
+    fac = synth.root_factors(s["points"], s["R0"], s["p0"], wl)
+    V = len(fac["coe"])
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    o = capi.default_options(); o.win_size = wl.win_size
+    small = capi.Context(o); small.push_dict(fac)
+    r1 = small.evaluate_only_residual(poses)
+    ev1, evec1, pa1 = small.read_back()
+    reps = (1 << 17) // V + 2
+    big = capi.Context(o)
+    for _ in range(reps):
+        big.push_dict(fac)
+    assert big.size() == reps * V > (1 << 17)
+    rb = big.evaluate_only_residual(poses)
+    assert abs(rb - reps * r1) < 1e-11 * abs(rb)
+    ev, evec, pa = big.read_back()
+    for k in (0, reps // 2, reps - 1):
+        sl = slice(k * V, (k + 1) * V)
+        assert np.array_equal(pa[sl], pa1)                       # same sums, same order of additions
+        assert np.abs(ev[sl] - ev1).max() < 1e-13 * max(1.0, np.abs(pa1[:, :6]).max() / 5)
+        n1 = evec[sl].reshape(V, 3, 3)[:, :, 0]; n2 = evec1.reshape(V, 3, 3)[:, :, 0]
+        assert np.abs(np.abs((n1 * n2).sum(1)) - 1).max() < 1e-12
+    # sub-ranges still work on the large store (acc_evaluate2-style head / end arguments)
+    f = oracle.Factor(wl.win_size); f.push_dict(fac)
+    ra = big.evaluate_only_residual(poses, 5, V - 3); rc = f.evaluate_only_residual(poses, 5, V - 3)
+    assert abs(ra - rc) < 1e-9 * abs(rc)      # (18k eigenvalues of ~1e-4, each good to eps x second moments ~1e-13: random-walk sum)

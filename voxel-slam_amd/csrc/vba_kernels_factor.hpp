@@ -224,7 +224,11 @@ struct ResCfg {
   static_assert(W * 12 <= NT, "one thread per pose scalar");
 };
 
-template <int W, int TV, bool STAMPS>
+// SPLIT: the large-store form of the pass.  When the store is far larger than the chip holds in flight (V >~ 1e5) the pass is
+// bandwidth-bound, and what counts is how many workgroups a CU keeps in their load phase: without the eigen-solve the kernel needs
+// ~48 instead of 76 VGPRs and its workgroups live half as long, so it stops after the frame sum (pcr_adds written) and
+// k_residual_eig below finishes the voxels one per lane in full waves.  The split re-reads pcr_adds (+80 B per voxel).
+template <int W, int TV, bool STAMPS, bool SPLIT = false>
 __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f, const double *__restrict__ poses, int head, int end,
                                                                   double *__restrict__ partial, const int *__restrict__ gate,
                                                                   long long *__restrict__ stamps) {
@@ -298,6 +302,7 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
       if (v < end) f.pcr[(size_t)k * vs + v] = a;
     }
   }
+  if (SPLIT) return;
   __syncthreads();
   if (STAMPS) st1 = clock64();
   double r = 0.0;
@@ -327,6 +332,35 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
       o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
     }
   }
+}
+
+// Second half of the split pass: one lane per voxel, 256-thread workgroups; reads pcr_adds + coe, writes eig_values / eig_vectors
+// (VM:308-318) and one residual partial per workgroup.
+__global__ __launch_bounds__(256) void k_residual_eig(FactorView f, int head, int end, double *__restrict__ partial, const int *__restrict__ gate) {
+  __shared__ double sw[4];
+  if (gate && *gate == 0) return;            // the device-resident LM loop has stopped
+  const int v = head + blockIdx.x * 256 + threadIdx.x;
+  const size_t vs = (size_t)f.vs;
+  double r = 0.0;
+  if (v < end) {
+    const double P00 = f.pcr[0 * vs + v], P01 = f.pcr[1 * vs + v], P02 = f.pcr[2 * vs + v], P11 = f.pcr[3 * vs + v], P12 = f.pcr[4 * vs + v];
+    const double P22 = f.pcr[5 * vs + v], s0 = f.pcr[6 * vs + v], s1 = f.pcr[7 * vs + v], s2 = f.pcr[8 * vs + v], Nv = f.pcr[9 * vs + v];
+    const double coe = f.coe[v];
+    double iN = __builtin_amdgcn_rcp(Nv);
+    iN = iN * (2.0 - Nv * iN);
+    iN = iN * (2.0 - Nv * iN);
+    const double b0 = s0 * iN, b1 = s1 * iN, b2 = s2 * iN;
+    double w0, w1, w2, V[9];
+    eig3_sym_dev(P00 * iN - b0 * b0, P01 * iN - b1 * b0, P02 * iN - b2 * b0, P11 * iN - b1 * b1, P12 * iN - b2 * b1, P22 * iN - b2 * b2, w0, w1, w2, V);
+    f.eigval[0 * vs + v] = w0; f.eigval[1 * vs + v] = w1; f.eigval[2 * vs + v] = w2;
+#pragma unroll
+    for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + v] = V[k];
+    r = coe * w0;
+  }
+  r = wave_sum_to_lane63(r);
+  if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
 // out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 16 outputs x 16 partial groups,
