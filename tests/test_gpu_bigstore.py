@@ -1,4 +1,4 @@
-"""The large-store form of the residual pass (two kernels beyond 2^17 voxels, see k_residual_s<..., SPLIT> / k_residual_eig): the same
+"""The large-store form of the residual pass (two kernels beyond 2^17 voxels: k_residual_s<..., SPLIT> + k_residual_eig): the same
 factors pushed 8x over must give 8x the residual and, voxel for voxel, the eigen-pairs and sums of the single-kernel pass."""
 import numpy as np
 import pytest

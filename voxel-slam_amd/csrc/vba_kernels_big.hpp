@@ -530,6 +530,52 @@ __global__ __launch_bounds__(256) void k_bigl_update(double *__restrict__ Ab, co
 }
 
 // ---------------------------------------------------------------- host side
+// diag(H) (the host-side LM bookkeeping needs only it and g: q1 of VM:465, Eigen's pivot order) and, for the edges of
+// HBA_add_edge (VS:2926-2951), the six diagonal entries of every 6x6 cross block: out[(i W + j) 6 + k] = H(6 i + k, 6 j + k).
+__global__ void k_big_getdiag(const double *__restrict__ H, int n, double *__restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = H[(size_t)r * n + r];
+}
+__global__ void k_big_blockdiag(const double *__restrict__ H, int W, double *__restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)W * W * 6) return;
+  const int k = (int)(t % 6), j = (int)((t / 6) % W), i = (int)(t / (6LL * W));
+  out[t] = H[(size_t)(6 * i + k) * (6 * (size_t)W) + 6 * j + k];
+}
+// Back substitution x = L^-T z on the device, 64 unknowns per step from the bottom (Ab: rows of L, row NP = z, row stride ld):
+//   k_bigl_bs_tri : one wave solves the 64x64 triangular diagonal block in place (lane j owns x[lo + j], v_readlane broadcasts);
+//   k_bigl_bs_gemv: every unknown above the block subtracts the block's contribution, z[j] -= sum_i L[i][j] x[i].
+// (The host version fetched the whole factor, 8 (NP+1) ld bytes — 47 MB at 400 submaps — for an O(n^2) loop.)
+__global__ __launch_bounds__(64) void k_bigl_bs_tri(double *__restrict__ Ab, int NP, int ld, int n, int lo) {
+  const int j = threadIdx.x, hi = (lo + 63 < n - 1) ? lo + 63 : n - 1;
+  double *z = Ab + (size_t)NP * ld;
+  double x = (lo + j <= hi) ? z[lo + j] : 0.0;
+  for (int i = hi; i > lo; i--) {
+    const double xi = readlane_f64(x, i - lo);
+    const double l = (lo + j < i) ? Ab[(size_t)i * ld + lo + j] : 0.0;
+    x -= l * xi;
+  }
+  if (lo + j <= hi) z[lo + j] = x;
+}
+__global__ __launch_bounds__(256) void k_bigl_bs_gemv(double *__restrict__ Ab, int NP, int ld, int n, int lo) {
+  __shared__ double xs[64];
+  const int hi = (lo + 63 < n - 1) ? lo + 63 : n - 1, cnt = hi - lo + 1;
+  double *z = Ab + (size_t)NP * ld;
+  if (threadIdx.x < 64) xs[threadIdx.x] = (int)threadIdx.x < cnt ? z[lo + threadIdx.x] : 0.0;
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= lo) return;
+  double acc = z[j];
+  const double *col = Ab + (size_t)lo * ld + j;
+#pragma unroll 8
+  for (int i = 0; i < cnt; i++) acc -= col[(size_t)i * ld] * xs[i];
+  z[j] = acc;
+}
+__global__ void k_bigl_bs_out(const double *__restrict__ Ab, int NP, int ld, int n, const int *__restrict__ ord, double *__restrict__ dxi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dxi[ord[i]] = Ab[(size_t)NP * ld + i];
+}
+
 struct BigStore {
   BigView b{};
   GbaBigView g{};
@@ -552,6 +598,7 @@ struct BigStore {
   int *h_cnt = nullptr;
   int *d_vcnt = nullptr, *d_fill = nullptr;
   double *d_Ab = nullptr, *d_Tb = nullptr; int *d_ord = nullptr;   // dense solver (allocated by big_build)
+  double *d_vec = nullptr;                                          // [3 n + 6 W W]: diag(H) | g copy | dxi | cross-block diagonals
   int NP = 0, ld = 0;
   void release() { for (Chunk &ck : chunks) hipFree(ck.base); chunks.clear(); if (h_cnt) hipHostFree(h_cnt); h_cnt = nullptr; b = BigView(); g = GbaBigView(); }
 };
@@ -625,7 +672,7 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
   BIGCHK(al((void **)&b.H, n6 * n6 * 8)); BIGCHK(al((void **)&b.g, n6 * 8)); BIGCHK(al((void **)&b.r, 8));
 
   s.NP = (int)((n6 + 7) / 8 * 8); s.ld = (int)((s.NP + 63) / 64 * 64);
-  BIGCHK(al((void **)&s.d_Ab, (size_t)(s.NP + 1) * s.ld * 8)); BIGCHK(al((void **)&s.d_Tb, (size_t)(s.NP + 1) * 8 * 8)); BIGCHK(al((void **)&s.d_ord, n6 * 4));
+  BIGCHK(al((void **)&s.d_Ab, (size_t)(s.NP + 1) * s.ld * 8)); BIGCHK(al((void **)&s.d_Tb, (size_t)(s.NP + 1) * 8 * 8)); BIGCHK(al((void **)&s.d_ord, n6 * 4)); BIGCHK(al((void **)&s.d_vec, ((size_t)3 * n6 + (size_t)6 * W * W) * 8));
   BIGCHK(hipMemsetAsync(s.d_fill, 0, (size_t)b.capV * 4, st));
   BIGCHK(hipMemsetAsync(b.vptr, 0, (size_t)(V + 1) * 4, st));
   int E = 0;
@@ -656,7 +703,8 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
 }
 
 // divide_thread (VM:347-389): H, g, r at `poses` on the host side buffers (full layout)
-inline int big_hessian(BigStore &s, hipStream_t st, const double *poses, double *H, double *gvec, double *r, std::string &err) {
+// Hessian pass on the sparse store: H (n x n) and g stay in HBM (the solver reads them there); the host gets diag(H), g and r.
+inline int big_hessian(BigStore &s, hipStream_t st, const double *poses, double *hdiag, double *gvec, double *r, std::string &err) {
   BigView &b = s.b;
   const size_t n6 = (size_t)6 * b.W;
   BIGCHK(hipMemcpyAsync(b.poses, poses, (size_t)b.W * 12 * 8, hipMemcpyHostToDevice, st));
@@ -669,12 +717,24 @@ inline int big_hessian(BigStore &s, hipStream_t st, const double *poses, double 
     if (nslice < 1) nslice = 1;
     hipLaunchKernelGGL(k_big_syrk, dim3(npair, nslice), dim3(256), 0, st, b, nt, nslice);
     hipLaunchKernelGGL(k_big_diag, dim3(b.W), dim3(256), 0, st, b);   // after the SYRK atomics on H (stream order)
-    BIGCHK(hipGetLastError());
   }
+  hipLaunchKernelGGL(k_big_getdiag, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, b.H, (int)n6, s.d_vec);
+  BIGCHK(hipGetLastError());
   BIGCHK(hipStreamSynchronize(st));
-  BIGCHK(hipMemcpyAsync(H, b.H, n6 * n6 * 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipMemcpyAsync(hdiag, s.d_vec, n6 * 8, hipMemcpyDeviceToHost, st));
   BIGCHK(hipMemcpyAsync(gvec, b.g, n6 * 8, hipMemcpyDeviceToHost, st));
   BIGCHK(hipMemcpyAsync(r, b.r, 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipStreamSynchronize(st));
+  return VBA_OK;
+}
+// the six diagonal entries of every 6x6 cross block of the Hessian of the last big_hessian (before the gauge): [W][W][6]
+inline int big_block_diagonals(BigStore &s, hipStream_t st, double *out, std::string &err) {
+  const int W = s.b.W;
+  const size_t n6 = (size_t)6 * W, cnt = (size_t)6 * W * W;
+  hipLaunchKernelGGL(k_big_blockdiag, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, s.b.H, W, s.d_vec + 3 * n6);
+  BIGCHK(hipGetLastError());
+  BIGCHK(hipStreamSynchronize(st));
+  BIGCHK(hipMemcpyAsync(out, s.d_vec + 3 * n6, cnt * 8, hipMemcpyDeviceToHost, st));
   BIGCHK(hipStreamSynchronize(st));
   return VBA_OK;
 }
@@ -692,8 +752,7 @@ inline int big_residual(BigStore &s, hipStream_t st, const double *poses, double
 }
 
 // (H + u D) dxi = -g with the gauge of VM:452-455, H / g = the device buffers of the last big_hessian (before the gauge).
-// ord = Eigen's pivot order (host), hd = diag after the gauge.  The O(n^3) factorisation runs on the device, the O(n^2) back
-// substitution on the host.
+// ord = Eigen's pivot order (host).  Factorisation and back substitution run on the device; the host gets dxi (n doubles).
 inline int big_solve(BigStore &s, hipStream_t st, const int *ord, double u, double *dxi, std::string &err) {
   const int n = 6 * s.b.W, NP = s.NP, ld = s.ld;
   BIGCHK(hipMemcpyAsync(s.d_ord, ord, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -707,19 +766,17 @@ inline int big_solve(BigStore &s, hipStream_t st, const int *ord, double u, doub
       if (nt > 0) hipLaunchKernelGGL(k_bigl_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, s.d_Ab, s.d_Tb, NP, ld, k0);
     }
   }
-  BIGCHK(hipGetLastError());
-  std::vector<double> L((size_t)(NP + 1) * ld);
-  BIGCHK(hipStreamSynchronize(st));
-  BIGCHK(hipMemcpyAsync(L.data(), s.d_Ab, L.size() * 8, hipMemcpyDeviceToHost, st));
-  BIGCHK(hipStreamSynchronize(st));
-  std::vector<double> x(n);
-  for (int j = 0; j < n; j++) x[j] = L[(size_t)NP * ld + j];                    // z = D^-1 L^-1 P (-g)
-  for (int i = n - 1; i >= 0; i--) {                                            // x = L^-T z
-    const double xi = x[i];
-    const double *row = &L[(size_t)i * ld];
-    for (int j = 0; j < i; j++) x[j] -= row[j] * xi;
+  // back substitution on the device, 64 unknowns per step from the bottom
+  for (int lo = ((n - 1) / 64) * 64; lo >= 0; lo -= 64) {
+    hipLaunchKernelGGL(k_bigl_bs_tri, dim3(1), dim3(64), 0, st, s.d_Ab, NP, ld, n, lo);
+    if (lo > 0) hipLaunchKernelGGL(k_bigl_bs_gemv, dim3((lo + 255) / 256), dim3(256), 0, st, s.d_Ab, NP, ld, n, lo);
   }
-  for (int i = 0; i < n; i++) dxi[ord[i]] = x[i];
+  double *d_dxi = s.d_vec + 2 * (size_t)n;
+  hipLaunchKernelGGL(k_bigl_bs_out, dim3((n + 255) / 256), dim3(256), 0, st, s.d_Ab, NP, ld, n, s.d_ord, d_dxi);
+  BIGCHK(hipGetLastError());
+  BIGCHK(hipStreamSynchronize(st));
+  BIGCHK(hipMemcpyAsync(dxi, d_dxi, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  BIGCHK(hipStreamSynchronize(st));
   return VBA_OK;
 }
 

@@ -225,9 +225,11 @@ struct ResCfg {
 };
 
 // SPLIT: the large-store form of the pass.  When the store is far larger than the chip holds in flight (V >~ 1e5) the pass is
-// bandwidth-bound, and what counts is how many workgroups a CU keeps in their load phase: without the eigen-solve the kernel needs
-// ~48 instead of 76 VGPRs and its workgroups live half as long, so it stops after the frame sum (pcr_adds written) and
-// k_residual_eig below finishes the voxels one per lane in full waves.  The split re-reads pcr_adds (+80 B per voxel).
+// throughput-bound; without the eigen-solve the kernel needs fewer registers and its workgroups live half as long, so it stops
+// after the frame sum (pcr_adds written) and k_residual_eig below finishes the voxels one per lane in full waves.  The split
+// re-reads pcr_adds (+80 B per voxel).  Measured at V = 9.9e5 (570 MB algorithmic, beyond the Infinity Cache): fused 208 us,
+// split 194 us; a persistent variant that walks the tiles with the next tile's first trip prefetched was SLOWER (205-227 us for
+// 768-2048 workgroups: three barriers per tile serialise what the dispatcher otherwise overlaps across many short workgroups).
 template <int W, int TV, bool STAMPS, bool SPLIT = false>
 __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f, const double *__restrict__ poses, int head, int end,
                                                                   double *__restrict__ partial, const int *__restrict__ gate,

@@ -96,8 +96,6 @@ struct vba_ctx {
   // device-resident LI-BA (vba_kernels_li.hpp)
   LiDev *d_li = nullptr;
   double *d_imu = nullptr, *d_himu = nullptr, *d_gimu = nullptr;
-  hipStream_t li_stream = nullptr;      // IMU factors run beside the lidar Hessian pass
-  hipEvent_t li_fork = nullptr, li_join = nullptr;
 
   MapStore map;
   GbaStore gba;
@@ -156,7 +154,9 @@ int factor_reserve(vba_ctx *c, int need) {
   if (need <= c->cap) return VBA_OK;
   int newcap = c->cap ? c->cap : 4096;
   while (newcap < need) newcap *= 2;
-  newcap = (newcap + 63) / 64 * 64;
+  // the SoA rows are `stride` doubles apart and every pass streams ~100 of them at the same offset: a power-of-two stride would
+  // put all those streams on the same HBM channels / cache sets, so the stride is skewed by an odd number of 512-byte blocks
+  newcap = (newcap + 63) / 64 * 64 + 64 * 33;
   const int W = c->opt.win_size;
   FactorView n = c->fv;
   n.vs = newcap; n.W = W;
@@ -239,7 +239,7 @@ int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int 
 #define VBA_K4_TV 32        // voxels per workgroup of the residual pass (tools/ builds 16 / 64 for comparison)
 #endif
 // number of workgroups (= residual partials) of the residual pass over n voxels.  Stores beyond kResidualSplit voxels take the
-// two-kernel form (see k_residual_s<..., SPLIT>): their partials come from k_residual_eig, one per 256 voxels.
+// two-kernel form (k_residual_s<..., SPLIT> + k_residual_eig): their partials come from k_residual_eig, one per 256 voxels.
 static const int kResidualSplit = 1 << 17;
 inline int residual_nb(int n) { return n > kResidualSplit ? (n + 255) / 256 : (n + VBA_K4_TV - 1) / VBA_K4_TV; }
 
@@ -484,9 +484,6 @@ void vba_destroy(vba_ctx *c) {
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
   if (c->d_k4part) hipFree(c->d_k4part);
-  if (c->li_fork) hipEventDestroy(c->li_fork);
-  if (c->li_join) hipEventDestroy(c->li_join);
-  if (c->li_stream) hipStreamDestroy(c->li_stream);
   if (c->d_imu) hipFree(c->d_imu);
   if (c->d_himu) hipFree(c->d_himu);
   if (c->d_gimu) hipFree(c->d_gimu);
@@ -797,9 +794,6 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     HIPCHK(c, hipMalloc((void **)&c->d_imu, (size_t)LI_MAX_W * 304 * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_himu, (size_t)LI_MAX_N * LI_MAX_N * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_gimu, (size_t)LI_MAX_N * sizeof(double)));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->li_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->li_fork, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->li_join, hipEventDisableTiming));
   }
   // upload: LM state (poses view), the IMU extras, the factors with cov^-1 in place of cov
   std::vector<double> poses((size_t)W * 12);
@@ -836,18 +830,12 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   }
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
-    // the IMU factors (one workgroup) run on a side stream under the lidar Hessian pass; both only read the LM state
-    static const bool no_side = getenv("VBA_LI_NO_SIDE_STREAM") != nullptr;
-    const bool side = !no_side;
-    if (side) {
-      HIPCHK(c, hipEventRecord(c->li_fork, c->stream));
-      HIPCHK(c, hipStreamWaitEvent(c->li_stream, c->li_fork, 0));
-    }
-    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, side ? c->li_stream : c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
-    if (side) HIPCHK(c, hipEventRecord(c->li_join, c->li_stream));
+    // the IMU factors (one workgroup) first, then the lidar Hessian pass, on the SAME stream.  A side stream for the IMU kernel
+    // (fork / join events around it) was measured slower: 209 vs 196 us per iteration — the two cross-stream dependencies cost
+    // more than the 28 us of the kernel they hid.
+    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
     if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);   // lidar part of divide_thread (+ all-reduce)
     if (st) { c->lm.active = false; return st; }
-    if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->li_join, 0));
     TimedSpan s1{};
     span_begin(c, "solve", s1);
     switch (W) {
@@ -1257,34 +1245,29 @@ int vba_gba_build(vba_ctx *c, int wdsize, const int *offsets, const double *pnt_
 
 // Lidar_BA_Optimizer::damping_iter (VM:422-497) for an arbitrary window: device Hessian / residual passes on the sparse
 // store, gauge + (H + uD) LDL^T + retraction on the host.
-static int big_damping_iter(vba_ctx *c, int W, double *poses, std::vector<double> &hess_out, double *resis2, int max_iter, int thd_num, int *is_converge) {
+// hdiag6_out: [W][W][6] = the six diagonal entries of every 6x6 block of *hess (all that HBA_add_edge reads of it, VS:2926-2951);
+// the n x n Hessian itself stays in HBM.
+static int big_damping_iter(vba_ctx *c, int W, double *poses, std::vector<double> &hdiag6_out, double *resis2, int max_iter, int thd_num, int *is_converge) {
   BigStore &S = c->big;
   const int n = 6 * W;
   if (S.b.V < thd_num) return VBA_ERR_TOO_FEW_VOXELS;                 // VM:399-403
-  std::vector<double> x(poses, poses + (size_t)W * 12), xt(x), Hess((size_t)n * n), JacT(n), A((size_t)n * n), rhs(n), dxi(n);
+  std::vector<double> x(poses, poses + (size_t)W * 12), xt(x), hd(n), JacT(n), dxi(n);
   double u = 0.01, v = 2, residual1 = 0, residual2 = 0;
   bool is_calc_hess = true, conv = true;
   c->trace.clear();
   for (int it = 0; it < max_iter; it++) {
     if (is_calc_hess) {
-      int st = big_hessian(S, c->stream, x.data(), Hess.data(), JacT.data(), &residual1, c->err);
+      int st = big_hessian(S, c->stream, x.data(), hd.data(), JacT.data(), &residual1, c->err);   // *hess = Hess (VM:446) stays on the device
       if (st) return st;
-      hess_out = Hess;                                                // *hess = Hess (VM:446)
+      for (int r = 0; r < 6; r++) { hd[r] = 1.0; JacT[r] = 0.0; }     // gauge VM:452-455 (k_bigl_setup applies it to the matrix)
     }
     if (it == 0) resis2[0] = residual1;
-    for (int r = 0; r < 6; r++) for (int k = 0; k < n; k++) { Hess[(size_t)r * n + k] = 0; Hess[(size_t)k * n + r] = 0; }
-    for (int r = 0; r < 6; r++) { Hess[(size_t)r * n + r] = 1; JacT[r] = 0; }
-    static const bool host_solve = getenv("VBA_BIG_HOST_SOLVE") != nullptr;   // diagnostic: Eigen-style LDLT on the host
-    if (host_solve) {
-      A = Hess;
-      for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * Hess[(size_t)r * n + r]; rhs[r] = -JacT[r]; }
-      vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), n);   // VM:458
-    } else {
+    {
       // pivot order of Eigen's LDLT (largest |stored diagonal| first, first index wins ties), then the device factorisation
       std::vector<int> ord(n);
       for (int r = 0; r < n; r++) ord[r] = r;
       std::vector<double> dabs(n);
-      for (int r = 0; r < n; r++) dabs[r] = std::fabs(Hess[(size_t)r * n + r] + u * Hess[(size_t)r * n + r]);
+      for (int r = 0; r < n; r++) dabs[r] = std::fabs(hd[r] + u * hd[r]);
       std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dabs[a] > dabs[b]; });
       int st2 = big_solve(S, c->stream, ord.data(), u, dxi.data(), c->err);
       if (st2) return st2;
@@ -1296,7 +1279,7 @@ static int big_damping_iter(vba_ctx *c, int W, double *poses, std::vector<double
       for (int k = 0; k < 3; k++) xt[12 * j + 9 + k] = x[12 * j + 9 + k] + dxi[6 * j + 3 + k];
     }
     double q1 = 0;
-    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * Hess[(size_t)r * n + r] * dxi[r] - JacT[r]);
+    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * hd[r] * dxi[r] - JacT[r]);
     q1 *= 0.5;
     int st = big_residual(S, c->stream, xt.data(), &residual2, c->err);
     if (st) return st;
@@ -1319,7 +1302,8 @@ static int big_damping_iter(vba_ctx *c, int W, double *poses, std::vector<double
   resis2[1] = residual2;
   std::memcpy(poses, x.data(), x.size() * sizeof(double));
   if (is_converge) *is_converge = conv ? 1 : 0;
-  return VBA_OK;
+  hdiag6_out.resize((size_t)6 * W * W);
+  return big_block_diagonals(S, c->stream, hdiag6_out.data(), c->err);   // b.H still holds the last evaluated Hessian (a rejected step does not recompute it)
 }
 
 int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *pnt_local, double *poses, double gba_voxel_size,
@@ -1353,7 +1337,7 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
   double *d_pl = c->d_refpts, *d_ref = c->d_refpts + c->refpts_doubles;
   if (n > 0) HIPCHK(c, hipMemcpyAsync(d_pl, pnt_local, (size_t)n * 3 * sizeof(double), hipMemcpyDefault, c->stream));
   GbaParams P = gba_params(c, gba_voxel_size, gba_min_eigen_value, gba_eigen_value_array);
-  std::vector<double> hess((size_t)n6 * n6, 0.0);
+  std::vector<double> hess(big ? 0 : (size_t)n6 * n6, 0.0), hd6;      // the any-window path keeps *hess in HBM and returns its block diagonals
   lap(0);
   const int up = 4;                                                       // VS:2866
   int converge_flag = 0;
@@ -1372,7 +1356,7 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
       st = big_build(c->big, c->stream, W, offsets, d_pl, poses, P, c->err);
       if (st) return st;
       lap(1);
-      st = big_damping_iter(c, W, poses, hess, resis, up, thread_num, &is_converge);
+      st = big_damping_iter(c, W, poses, hd6, resis, up, thread_num, &is_converge);
     }
     if (st) return st;
     lap(2);
@@ -1389,7 +1373,7 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
       bool isAdd = true;
       double v6[6];
       for (int k = 0; k < 6; k++) {
-        const double hc = std::fabs(hess[(size_t)(6 * i + k) * n6 + 6 * j + k]);
+        const double hc = std::fabs(big ? hd6[((size_t)i * W + j) * 6 + k] : hess[(size_t)(6 * i + k) * n6 + 6 * j + k]);
         if (hc < 1e-6) { isAdd = false; break; }
         v6[k] = 1.0 / hc;
       }
