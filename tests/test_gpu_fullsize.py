@@ -238,4 +238,4 @@ def test_fullsize_rebuild_is_deterministic(capi, synth, scans):
     assert np.allclose(a[:, 22:32], b[:, 22:32], rtol=1e-11, atol=1e-13)
     # (H sums ~2e5 slot terms that each inherit the last-bit differences of the atomically accumulated cluster sums)
     assert np.abs(hs[0][0] - hs[1][0]).max() < 1e-10 * np.abs(hs[0][0]).max()
-    assert abs(hs[0][2] - hs[1][2]) < 1e-12 * abs(hs[0][2])
+    assert abs(hs[0][2] - hs[1][2]) < 1e-10 * abs(hs[0][2])      # 18k eigenvalues of ~1e-4, each good to eps x second moments

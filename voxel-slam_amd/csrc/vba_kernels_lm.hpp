@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
     for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dxs[6 * tid + 3 + k];
   }
   double q = tid < n ? dxs[tid] * (u * hd[tid] * dxs[tid] - gs[tid]) : 0.0;                              // VM:465
-  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-  if ((tid & 63) == 0) red8[tid >> 6] = q;
+  q = wave_sum_to_lane63(q);                                  // DPP adds (vba_kernels_factor.hpp), no LDS round trips
+  if ((tid & 63) == 63) red8[tid >> 6] = q;
   __syncthreads();
   if (tid == 0) s->q1 = 0.5 * (red8[0] + red8[1] + red8[2] + red8[3]);
   if (stamps) stamps[5] = clock64();

@@ -642,7 +642,15 @@ int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
 int vba_lm_refresh_eigen(vba_ctx *c) {
   if (!c->lm.active) return VBA_ERR_BAD_ARG;
   const double *x_dev = reinterpret_cast<const double *>(reinterpret_cast<char *>(c->d_lm) + offsetof(LmDev, x));
-  return residual_pass(c, x_dev, nullptr, 0, c->nvox, c->d_scal);
+  if (c->nvox <= 0) return VBA_OK;
+  // only the pass' side effect is wanted (eig_values / eig_vectors / pcr_adds at the begin poses): its partials are not summed
+  if ((size_t)residual_nb(c->nvox) > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
+  TimedSpan s1{};
+  span_begin(c, "residual", s1);
+  launch_residual(c, x_dev, nullptr, 0, c->nvox);
+  span_end(c, "residual", s1);
+  HIPCHK(c, hipGetLastError());
+  return VBA_OK;
 }
 
 // One trip through the loop body VM:441-494, enqueued without host synchronisation unless the caller asks for the flags.
