@@ -159,7 +159,8 @@ def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=56):
     gbs = by / (us * 1e-6) / 1e9
     ctx.close()
     return {"copies": copies, "voxels": V, "occupied_frames_per_voxel": occ, "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch": by,
-            "layout_extra_bytes_per_launch": V * (W - occ) * 8, "exceeds_2x_infinity_cache": bool(by >= 2 * 256 * 2 ** 20),
+            "layout_extra_bytes_per_launch": V * 4 + V * 80, "layout_extra_note": "occupancy mask + pcr_adds re-read by the second kernel of the large-store form",
+            "exceeds_2x_infinity_cache": bool(by >= 2 * 256 * 2 ** 20),
             "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
 
 
@@ -582,10 +583,10 @@ def main():
     V_local = ctx.size()
     occ = ctx.factor_occupancy()     # occupied (voxel, frame) slots per voxel
     # algorithmic bytes: residual pass reads (W_occ+1)*80 + 8, writes 176 per voxel; the SoA layout additionally
-    # reads the N of every EMPTY slot (8 B each) to find the occupied ones: reported separately as layout overhead.
+    # reads a 4-byte occupancy mask per voxel to find the occupied slots: reported separately as layout overhead.
     # Hessian pass reads W_occ*80 + 80 + 96 + 8 per voxel (fixed cluster row is not read: it only needs pcr_add's N, v).
     bytes_res = alg_bytes_residual(V_local, occ)
-    bytes_res_layout = V_local * (W - occ) * 8
+    bytes_res_layout = V_local * 4            # the 4-byte occupancy mask per voxel that tells the pass which slots to read
     bytes_hes = V_local * (occ * 80 + 80 + 96 + 8)
     flops_hes = V_local * (occ * 600 + 2 * 3 * (6 * W) * (6 * W + 1) / 2.0)      # slot preparation + the G^T C G contraction
     res_us_raw = t_res / max(n_res, 1)

@@ -17,6 +17,8 @@ struct FactorView {
   double *eigval;  // [3][vs]
   double *eigvec;  // [9][vs]       row-major r*3+c, column c = eigenvector c
   double *pcr;     // [10][vs]      pcr_adds
+  unsigned int *occ;   // [vs]      bit i set <=> slot (voxel, frame i) holds points (cl N != 0): what the residual pass tests instead of
+                       //           reading the N of all W slots (4 B per voxel instead of 8 W); kept current by k_factor_mask
   int vs;          // voxel stride (capacity)
   int W;
 };
@@ -139,6 +141,17 @@ __global__ void k_soa_to_aos_out(FactorView f, int n, double *__restrict__ eig_v
   }
 }
 
+// occupancy masks of voxels [base, base + n): run after every write of the cluster rows (push_voxels, the map's / the GBA octree's extraction)
+__global__ void k_factor_mask(FactorView f, int base, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int v = base + t;
+  const size_t vs = (size_t)f.vs;
+  unsigned int m = 0;
+  for (int i = 0; i < f.W; i++) m |= (f.cl[((size_t)9 * f.W + i) * vs + v] != 0.0) ? (1u << i) : 0u;
+  f.occ[v] = m;
+}
+
 __global__ void k_count_slots(FactorView f, int n, unsigned long long *out) {
   const long long tot = (long long)n * f.W;
   unsigned long long c = 0;
@@ -165,8 +178,9 @@ __global__ __launch_bounds__(256) void k_calib_read8(const double *__restrict__ 
 // Algorithmic traffic per voxel: read (W_occ + 1) * 80 + 8 B, write 176 B.
 //
 // Workgroup = TV voxels x W frames, one thread per (voxel, frame) SLOT; wave 0's first TV lanes double as the voxel threads.
-//   trip 1: every slot thread reads its N (the occupancy test), the voxel threads the fixed cluster + coe, W*12 threads the poses;
-//   trip 2: occupied slots read their 9 other scalars (empty slots cost 8 B, not 80 B);
+//   trip 1: every slot thread reads its voxel's occupancy mask (4 B, shared by the W slot threads of the voxel), thread (voxel, k)
+//           scalar k of the fixed cluster, row 0 coe, W*12 threads the poses;
+//   trip 2: occupied slots read their 10 scalars (empty slots cost nothing);
 //   slot threads transform their cluster (~95 f64 operations) and park the 10 world-frame scalars in LDS;
 //   thread (voxel, k) adds scalar k of the W frames to the fixed cluster IN FRAME ORDER (the reference's order, VM:297-305: the
 //   sum does not depend on the launch) and writes pcr_adds (VM:319); the voxel threads solve the 3x3 eigen-problem
@@ -248,21 +262,23 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
   const int fic = fi < W ? fi : W - 1;
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
   if (STAMPS) st0 = clock64();
-  // ---- trip 1: N of the slot, this thread's scalars of the fixed cluster, coe (row 0), the poses
-  double n = f.cl[9 * fs + (size_t)fic * vs + vc];
+  // ---- trip 1: the voxel's occupancy mask, this thread's scalars of the fixed cluster, coe (row 0), the poses
+  const unsigned int occm = f.occ[vc];
   const double pose_s = poses[tid < W * 12 ? tid : 0];
   double acc[C::KPT];
 #pragma unroll
   for (int j = 0; j < C::KPT; j++) { const int k = fi + j * C::NF; acc[j] = f.fix[(size_t)(k < 10 ? k : 9) * vs + vc]; }
   double coe = f.coe[vc];
-  asm volatile("" : "+v"(n), "+v"(coe), "+v"(acc[0]));          // keep the loads above the exit (they would be sunk below it)
+  unsigned int occv = occm;
+  asm volatile("" : "+v"(occv), "+v"(coe), "+v"(acc[0]));       // keep the loads above the exit (they would be sunk below it)
   if (gate_v == 0) return;
   if (tid < W * 12) sp[tid] = pose_s;
-  // ---- trip 2: the 9 other scalars of an occupied slot (empty slots cost 8 B, not 80 B)
-  const bool occ = fi < W && v < end && n != 0.0;
-  double c[9];
+  // ---- trip 2: the 10 scalars of an occupied slot (an empty slot costs nothing beyond its mask bit)
+  const bool occ = fi < W && v < end && ((occv >> fic) & 1u);
+  double c[9], n = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; k++) c[k] = occ ? f.cl[(size_t)k * fs + (size_t)fi * vs + v] : 0.0;
+  if (occ) n = f.cl[9 * fs + (size_t)fi * vs + v];
   __syncthreads();
   if (occ) {
     const double pxx = c[0], pxy = c[1], pxz = c[2], pyy = c[3], pyz = c[4], pzz = c[5];
@@ -328,7 +344,7 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
   if (tid < 64) {
     r = wave_sum_to_lane63(r);
     if (tid == 63) partial[blockIdx.x] = r;
-    if (STAMPS && tid == 63 && blockIdx.x < 2048) {
+    if (STAMPS && tid == 0 && blockIdx.x < 2048) {
       st3 = clock64();
       long long *o = stamps + (size_t)blockIdx.x * 4;
       o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;

@@ -170,11 +170,21 @@ int factor_reserve(vba_ctx *c, int need) {
       HIPCHK(c, hipMemcpy2DAsync(*np[k], (size_t)newcap * sizeof(double), op[k], (size_t)c->cap * sizeof(double),
                                  (size_t)c->nvox * sizeof(double), rows[k], hipMemcpyDeviceToDevice, c->stream));
   }
+  unsigned int *oocc = c->fv.occ;
+  HIPCHK(c, hipMalloc((void **)&n.occ, (size_t)newcap * sizeof(unsigned int)));
+  HIPCHK(c, hipMemsetAsync(n.occ, 0, (size_t)newcap * sizeof(unsigned int), c->stream));
+  if (c->nvox > 0 && oocc) HIPCHK(c, hipMemcpyAsync(n.occ, oocc, (size_t)c->nvox * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int k = 0; k < 6; k++) if (op[k]) hipFree(op[k]);
+  if (oocc) hipFree(oocc);
   c->fv = n;
   c->cap = newcap;
   return VBA_OK;
+}
+
+// the occupancy masks of voxels [base, base + n) follow every write of the cluster rows
+void factor_update_mask(vba_ctx *c, int base, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_factor_mask, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fv, base, n);
 }
 
 int upload_poses(vba_ctx *c, const double *poses) {
@@ -489,6 +499,7 @@ void vba_destroy(vba_ctx *c) {
   if (c->d_gimu) hipFree(c->d_gimu);
   double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out, c->d_full, c->d_scal};
   for (double *q : p) if (q) hipFree(q);
+  if (c->fv.occ) hipFree(c->fv.occ);
   if (c->d_stage) hipFree(c->d_stage);
   if (c->h_pin) hipHostFree(c->h_pin);
   if (c->d_lm) hipFree(c->d_lm);
@@ -530,6 +541,7 @@ int vba_factor_push_voxels(vba_ctx *c, int n, const double *clusters, const doub
   int nb = (int)((tot + 255) / 256);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_aos_to_soa, dim3(nb), dim3(256), 0, c->stream, c->fv, c->nvox, n, d_cl, d_fix, d_coe, d_ev, d_evec, d_pcr);
+  factor_update_mask(c, c->nvox, n);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // caller's arrays may go away
   c->nvox += n;
@@ -1230,6 +1242,7 @@ static int gba_build_into_store(vba_ctx *c, int wdsize, const int *offsets, cons
   if (nf > 0) {
     const int nn = c->gba.h_cnt[GCNT_NODES] < c->gba.v.cap ? c->gba.h_cnt[GCNT_NODES] : c->gba.v.cap;
     hipLaunchKernelGGL(k_gba_extract, dim3((nn + 255) / 256, 10 * wdsize + 33), dim3(256), 0, c->stream, c->gba.v, c->fv);
+    factor_update_mask(c, 0, nf);
     HIPCHK(c, hipGetLastError());
   }
   span_end(c, "gba_build", sp);
@@ -1831,6 +1844,7 @@ int vba_map_recut(vba_ctx *c, int win_count, const double *poses, int multi) {
   st = factor_reserve(c, nf > 0 ? nf : 1);
   if (st) return st;
   st = map_extract_factors(c->map, c->stream, c->fv, c->err, &nf);
+  factor_update_mask(c, 0, nf);
   span_end(c, "recut", sp);
   if (st) return st;
   c->nvox = nf;
