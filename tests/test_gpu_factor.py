@@ -203,7 +203,7 @@ def test_li_ba_damping_iter_parity(capi, oracle, synth, gravity, name):
 @pytest.mark.parametrize("W", [2, 3, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16])
 def test_lm_all_window_sizes(capi, oracle, synth, W):
     """Every supported window size through the device-resident optimisers (blocked LDL^T: 1..6 accumulator tiles per side,
-    one or two 64-row back-substitution blocks; LI-BA on the device up to W = 10, host solve above)."""
+    one or two 64-row back-substitution blocks; LI-BA: L in the LDS up to W = 10, in device scratch above)."""
     import dataclasses
     wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], name="room_w%d" % W, win_size=W)
     s = synth.make_scans(wl)

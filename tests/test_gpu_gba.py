@@ -197,7 +197,8 @@ def test_hba_global_at_scale(oracle):
     # 1 / |H_kk| of a cross block: a sum of ~1e5 signed voxel terms — the few entries that nearly cancel carry the summation-order
     # difference relative to their small value (one of 10530 weights differs by 1.4e-4; all others < 1e-5)
     np.testing.assert_allclose(e1[:, 14:], o1[:, 14:], rtol=1e-3)
-    assert np.quantile(np.abs(e1[:, 14:] / o1[:, 14:] - 1), 0.999) < 1e-5
+    rel = np.abs(e1[:, 14:] / o1[:, 14:] - 1)
+    assert np.quantile(rel, 0.99) < 1e-5 and np.quantile(rel, 0.999) < 1e-4 and np.median(rel) < 1e-8
     r2 = oracle.hba_add_edge(subs, x0[firsts], cfg, 2, 5, want_cloud=False)
     assert r2["status"] == 0
     o2 = r2["edges"].copy()

@@ -455,6 +455,13 @@ constexpr int hess2_tv(int W) {   // voxels per tile: ~256 / W slot threads = ex
 }
 constexpr int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
 
+__device__ __forceinline__ double rcp_f64(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
 template <int W>
 struct HessCfg2 {
   static constexpr int TV = hess2_tv(W);
@@ -591,15 +598,16 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
       double ck1 = 0.0, ck2 = 0.0, ck3 = 0.0;
       if (q.valid) {
         const double coe = q.coe, l0 = q.l0, NN = q.NN;
-        const double c1 = 2.0 / (l0 - q.l1), c2 = 2.0 / (l0 - q.l2);      // VM:201
-        ck1 = coe * c1; ck2 = coe * c2; ck3 = coe * (-2.0 / NN / NN);
+        // reciprocals by v_rcp_f64 + two Newton steps (full f64 precision to an ulp) instead of five IEEE divisions per slot
+        const double inn = rcp_f64(NN);
+        const double c1 = 2.0 * rcp_f64(l0 - q.l1), c2 = 2.0 * rcp_f64(l0 - q.l2);      // VM:201
+        ck1 = coe * c1; ck2 = coe * c2; ck3 = coe * (-2.0 * inn * inn);
         if (fi == 0) rres += coe * l0;                                    // VM:275
         const double n = q.n;
         if (n != 0.0) {
           const double pxx = q.c[0], pxy = q.c[1], pxz = q.c[2], pyy = q.c[3], pyz = q.c[4], pzz = q.c[5];
           const double vx = q.c[6], vy = q.c[7], vz = q.c[8];
           const double u00 = q.U[0], u01 = q.U[1], u02 = q.U[2], u10 = q.U[3], u11 = q.U[4], u12 = q.U[5], u20 = q.U[6], u21 = q.U[7], u22 = q.U[8];
-          const double inn = 1.0 / NN;
           const double bx = q.vs0 * inn, by = q.vs1 * inn, bz = q.vs2 * inn;                                      // vBar (VM:190)
           const double *R = sp + 12 * fi;
           const double k0 = u00, k1 = u10, k2 = u20;
@@ -668,8 +676,13 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
     __syncthreads();
     if (stamp_i < 12) { VBA_STAMP(stamp_i); stamp_i++; }
     // ---------------- phase B: MFMA contraction of the tile's NK rows; unit = (16x16 tile, k-split)
+    // The wave's UPW units are advanced ROUND-ROBIN, one k-step each per round: consecutive MFMAs then write different
+    // accumulators (a chain on one accumulator ran at ~115 cycles per v_mfma_f64_16x16x4_f64 — its dependent latency — against
+    // 64 cycles of issue), and the operands of round r + 1 are requested from LDS before the MFMAs of round r are issued (left
+    // to itself the compiler waits for every operand pair right before its MFMA).
     {
       const int kr = lane >> 4, cl = lane & 15;
+      const double *gap[C::UPW], *gbp[C::UPW], *ckp[C::UPW];
 #pragma unroll
       for (int t = 0; t < C::UPW; t++) {
         const int unit = wv * C::UPW + t;
@@ -678,17 +691,27 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
         while (p >= C::NT16 - ta) { p -= C::NT16 - ta; ta++; }
         const int tb = ta + p;
         const int kb = ksp * C::KSTEPS * 4;
-        const double *ga = G + (size_t)(kb + kr) * C::GS + 16 * ta + cl;
-        const double *gb = G + (size_t)(kb + kr) * C::GS + 16 * tb + cl;
-        const double *ck = cK + kb + kr;
-        v4f64 a4 = acc[t];
+        gap[t] = G + (size_t)(kb + kr) * C::GS + 16 * ta + cl;
+        gbp[t] = G + (size_t)(kb + kr) * C::GS + 16 * tb + cl;
+        ckp[t] = cK + kb + kr;
+      }
+      double ar[C::UPW], cr[C::UPW], br[C::UPW];
 #pragma unroll
-        for (int k = 0; k < C::KSTEPS * 4; k += 4) {
-          const double av = ga[(size_t)k * C::GS] * ck[k];
-          const double bv = gb[(size_t)k * C::GS];
-          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a4, 0, 0, 0);
+      for (int t = 0; t < C::UPW; t++) { ar[t] = gap[t][0]; cr[t] = ckp[t][0]; br[t] = gbp[t][0]; }
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ks++) {
+        double av[C::UPW], bv[C::UPW];
+#pragma unroll
+        for (int t = 0; t < C::UPW; t++) { av[t] = ar[t] * cr[t]; bv[t] = br[t]; }
+        if (ks + 1 < C::KSTEPS) {
+          const int k = 4 * (ks + 1);
+#pragma unroll
+          for (int t = 0; t < C::UPW; t++) { ar[t] = gap[t][(size_t)k * C::GS]; cr[t] = ckp[t][k]; br[t] = gbp[t][(size_t)k * C::GS]; }
         }
-        acc[t] = a4;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < C::UPW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();

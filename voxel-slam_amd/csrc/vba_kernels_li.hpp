@@ -2,15 +2,16 @@
 //   k_hessian -> k_reduce -> [all-reduce] -> k_li_imu (IMU factors: joc^T cov^-1 joc, VM:551-567) -> k_li_solve
 //   -> k_residual -> k_li_update (IMU residual at the trial states + accept/reject, VM:675-706)
 // The lidar part reuses the pose-only passes unchanged (they read the R,p view kept in LmDev); everything the IMU adds
-// lives in LiDev and three flat device arrays.  Supported on the device for W <= 10 (n = 15 W + 3 <= 153: the packed
-// factor of the (n+1)-row augmented system fits the 160 KB LDS); larger windows use the host solve in voxelba.hip.
+// lives in LiDev and three flat device arrays.  Up to W = 10 (n = 15 W + 3 <= 153) the packed factor of the (n+1)-row
+// augmented system fits the 160 KB LDS; for W = 11..16 (n <= 243) the same kernel keeps the staged matrix and L in a
+// device scratch buffer (GL = true) and only the panel buffers in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vba_hostmath.hpp"
 
 namespace vba {
 
-constexpr int LI_MAX_W = 10;
+constexpr int LI_MAX_W = 16;
 constexpr int LI_MAX_N = 15 * LI_MAX_W + 3;
 
 struct LiDev {
@@ -201,15 +202,16 @@ __device__ __forceinline__ double li_hfull(const double *__restrict__ himu, cons
 }
 
 // (H + u D) dxi = -g for the 15W(+3) system in Eigen-LDLT pivot order, then the retraction of VM:661-671 / 921-934.
-template <int W, int NT>
+template <int W, int NT, bool GL>
 __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const double *__restrict__ red, double *__restrict__ raw, int copy_raw,
                                                  const double *__restrict__ himu, const double *__restrict__ gimu, double *__restrict__ imu,
-                                                 int n, int gauge, int grav, double coef) {
+                                                 int n, int gauge, int grav, double coef, double *__restrict__ lscratch) {
   using C2 = HessCfg2<W>;
   constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
   using LC = LdltCfg<NP>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *Lst = lds, *Tp = Lst + LC::LTOT, *P = Tp + NP * LC::LS;
+  // GL: L (and the staged matrix before it) in device memory — written and read by this one workgroup only, ordered by its barriers
+  double *Lst = GL ? lscratch : lds, *Tp = GL ? lds : Lst + LC::LTOT, *P = Tp + NP * LC::LS;
   double *hd = P + NP * 8, *gs = hd + NMAX, *dsh = gs + NMAX, *xs = dsh + NMAX, *dxs = xs + NP, *red8 = dxs + NMAX;
   int *ord = (int *)(red8 + 32);
   const int tid = threadIdx.x;

@@ -122,10 +122,14 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
       const double *la = Lk + (act ? (16 * tti[u] + lc - k0) : 0) * LS + lr, *tb = Tp + (act ? (16 * ttj[u] + lc) : k0) * LS + lr;
       la0[u] = la[0]; la1[u] = la[4]; tb0[u] = tb[0]; tb1[u] = tb[4];
     }
+    // (first the first half of the rank-8 update on every live tile, then the second: two MFMAs in a row on ONE accumulator run at
+    //  the instruction's dependent latency, ~115 cycles, instead of its 64-cycle issue rate)
+#pragma unroll
+    for (int u = 0; u < TPW; u++)
+      if ((w + NW * u < C::NTILES) && (ttj[u] >= tjn)) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la0[u], tb0[u], acc[u], 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < TPW; u++) {
       if ((w + NW * u < C::NTILES) && (ttj[u] >= tjn)) {    // wave-uniform
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la0[u], tb0[u], acc[u], 0, 0, 0);
         acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la1[u], tb1[u], acc[u], 0, 0, 0);
         if (ttj[u] == tjn && lc >= cb0 && lc < cb0 + 8)
 #pragma unroll

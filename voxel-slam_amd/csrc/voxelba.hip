@@ -105,6 +105,7 @@ struct vba_ctx {
   double *d_refpts = nullptr;     // submap cloud staging (HBA_add_edge)
   size_t refpts_doubles = 0;
   double *d_lipack = nullptr; size_t lipack_doubles = 0;       // li_ba_device: results gathered for one D2H copy
+  double *d_liscr = nullptr; size_t liscr_doubles = 0;         // k_li_solve at W > 10: staged matrix / L outside the LDS
   double *d_hba_all = nullptr; size_t hba_all_doubles = 0;   // vba_hba_global: keyframe clouds + submap clouds, kept across calls
 
   void set_error(const std::string &s) { err = s; }
@@ -490,6 +491,7 @@ void vba_destroy(vba_ctx *c) {
   c->big.release();
   if (c->d_hba_all) hipFree(c->d_hba_all);
   if (c->d_lipack) hipFree(c->d_lipack);
+  if (c->d_liscr) hipFree(c->d_liscr);
   for (int i = 0; i < 2; i++) if (c->d_kdtree[i]) hipFree(c->d_kdtree[i]);
   if (c->d_refpts) hipFree(c->d_refpts);
   if (c->d_li) hipFree(c->d_li);
@@ -789,18 +791,27 @@ int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
 
 // ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity on the device
 extern "C++" {
-template <int W, int NT = 512>
+template <int W, int NT = (W > 10 ? 1024 : 512)>
 static void launch_li_solve(vba_ctx *c, int copy_raw, int n, int gauge, int grav) {
   constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
-  constexpr size_t lds = ((size_t)LdltCfg<NP>::DOUBLES + 4 * NMAX + NP + 32) * 8 + (size_t)NMAX * 4 + 64;
+  constexpr bool GL = W > 10;                    // L of the 15 W + 3 system exceeds the LDS: it lives in c->d_liscr
+  constexpr size_t l_doubles = (size_t)LdltCfg<NP>::LTOT > (size_t)NMAX * (NMAX + 1) / 2 ? (size_t)LdltCfg<NP>::LTOT : (size_t)NMAX * (NMAX + 1) / 2;
+  constexpr size_t lds = ((GL ? (size_t)LdltCfg<NP>::DOUBLES - LdltCfg<NP>::LTOT : (size_t)LdltCfg<NP>::DOUBLES) + 4 * NMAX + NP + 32) * 8 + (size_t)NMAX * 4 + 64;
+  static_assert(GL || l_doubles == (size_t)LdltCfg<NP>::LTOT, "the staged triangle must fit the region of L");
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  hipLaunchKernelGGL((k_li_solve<W, NT>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
-                     c->opt.imu_coef);
+  if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  if (GL && c->liscr_doubles < l_doubles) {
+    if (c->d_liscr) hipFree(c->d_liscr);
+    c->d_liscr = nullptr; c->liscr_doubles = 0;
+    if (hipMalloc((void **)&c->d_liscr, l_doubles * sizeof(double)) != hipSuccess) return;    // (the launch below then fails and is reported)
+    c->liscr_doubles = l_doubles;
+  }
+  hipLaunchKernelGGL((k_li_solve<W, NT, GL>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
+                     c->opt.imu_coef, c->d_liscr);
 }
 }  // extern "C++"
 
-static bool li_device_supported(int W) { return W == 2 || W == 3 || W == 4 || W == 5 || W == 6 || W == 8 || W == 10; }
+static bool li_device_supported(int W) { return W >= 2 && W <= LI_MAX_W; }
 
 static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
   static const bool want_times = getenv("VBA_LI_TIMES") != nullptr;   // diagnostic: host-side phases of one call
@@ -846,7 +857,8 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16 + (size_t)F * 225) * sizeof(double);
   {
     static bool attr_set = false;      // W = 10 with gravity: 88 KB
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * 9 * 15 * 33 + 2 * 9 * 15 + 9 + 16 + 9 * 225) * sizeof(double))); attr_set = true; }
+    constexpr int FM = LI_MAX_W - 1;
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * FM * 15 * 33 + 2 * FM * 15 + FM + 16 + FM * 225) * sizeof(double))); attr_set = true; }
   }
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
@@ -864,12 +876,20 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
       case 4: launch_li_solve<4>(c, copy_raw, n, h.gauge, h.gravity); break;
       case 5: launch_li_solve<5>(c, copy_raw, n, h.gauge, h.gravity); break;
       case 6: launch_li_solve<6>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 7: launch_li_solve<7>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 9: launch_li_solve<9>(c, copy_raw, n, h.gauge, h.gravity); break;
       case 8: launch_li_solve<8>(c, copy_raw, n, h.gauge, h.gravity); break;
       case 10: {
         static const int nt = getenv("VBA_LI_NT") ? atoi(getenv("VBA_LI_NT")) : 512;      // tuning knob
         if (nt == 256) launch_li_solve<10, 256>(c, copy_raw, n, h.gauge, h.gravity); else if (nt == 1024) launch_li_solve<10, 1024>(c, copy_raw, n, h.gauge, h.gravity); else launch_li_solve<10, 512>(c, copy_raw, n, h.gauge, h.gravity);
         break;
       }
+      case 11: launch_li_solve<11>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 12: launch_li_solve<12>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 13: launch_li_solve<13>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 14: launch_li_solve<14>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 15: launch_li_solve<15>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 16: launch_li_solve<16>(c, copy_raw, n, h.gauge, h.gravity); break;
       default: c->lm.active = false; return VBA_ERR_UNSUPPORTED_WINDOW;
     }
     span_end(c, "solve", s1);
@@ -966,130 +986,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
 
 // ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity (VM:504-976)
 int vba_li_ba_damping_iter(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
-  {
-    static const bool force_host = getenv("VBA_LI_HOST") != nullptr;     // diagnostic: the earlier host-side IMU + solve
-    if (!force_host && li_device_supported(c->opt.win_size)) return li_ba_device(c, states, imus, gravity, max_iter, hess, resis2);
-  }
-  const int W = c->opt.win_size, n6 = 6 * W, nout = nout_of(W), V = c->nvox;
-  const int DIM = VBA_DIM;
-  const int imu_leng = W * DIM + (gravity ? 3 : 0);
-  const int nb = gravity ? 33 : 30;
-  const double imu_coef = c->opt.imu_coef;
-  vbh::State *xs = reinterpret_cast<vbh::State *>(states);
-  vbh::ImuPre *fac = reinterpret_cast<vbh::ImuPre *>(imus);
-  std::vector<vbh::State> x(xs, xs + W), xt(xs, xs + W);
-  std::vector<double> Hess((size_t)imu_leng * imu_leng), JacT(imu_leng), dxi(imu_leng), saved((size_t)imu_leng * imu_leng, 0.0);
-  std::vector<double> jtj((size_t)nb * nb), gg(nb), lid(nout), poses((size_t)W * 12);
-  double u = 0.01, v = 2, residual1 = 0, residual2 = 0, resis_first = 0;
-  bool is_calc_hess = true;
-  if (!gravity) max_iter = 3;                                         // VM:643
-  const int gauge = gravity ? 6 : DIM;                                // VM:653-656 vs VM:906-909
-  c->trace.clear();
-  auto imu_resid = [&](std::vector<vbh::State> &s) {                  // VM:605-607 / VM:851-854
-    double r = 0;
-    for (int i = 0; i < W - 1; i++) r += vbh::imu_evaluate(fac[i], s[i], s[i + 1], gravity != 0, false, nullptr, nullptr);
-    return r * (imu_coef * 0.5);
-  };
-  for (int it = 0; it < max_iter; it++) {
-    if (is_calc_hess) {                                               // divide_thread VM:519-584 / VM:746-825
-      states_to_poses(reinterpret_cast<double *>(x.data()), W, poses.data());
-      int st = eval_hessian_dev(c, poses.data(), 0, V);               // device pass runs while the host does the IMU part
-      if (st) return st;
-      std::fill(Hess.begin(), Hess.end(), 0.0); std::fill(JacT.begin(), JacT.end(), 0.0);
-      double residual = 0;
-      for (int i = 0; i < W - 1; i++) {
-        residual += vbh::imu_evaluate(fac[i], x[i], x[i + 1], gravity != 0, true, jtj.data(), gg.data());
-        for (int r = 0; r < 2 * DIM; r++) {
-          for (int k = 0; k < 2 * DIM; k++) Hess[(size_t)(i * DIM + r) * imu_leng + i * DIM + k] += jtj[(size_t)r * nb + k];
-          JacT[i * DIM + r] += gg[r];
-        }
-        if (gravity) {                                                // VM:788-795
-          for (int r = 0; r < 2 * DIM; r++)
-            for (int k = 0; k < 3; k++) {
-              Hess[(size_t)(i * DIM + r) * imu_leng + imu_leng - 3 + k] += jtj[(size_t)r * nb + 2 * DIM + k];
-              Hess[(size_t)(imu_leng - 3 + k) * imu_leng + i * DIM + r] += jtj[(size_t)(2 * DIM + k) * nb + r];
-            }
-          for (int r = 0; r < 3; r++) {
-            for (int k = 0; k < 3; k++) Hess[(size_t)(imu_leng - 3 + r) * imu_leng + imu_leng - 3 + k] += jtj[(size_t)(2 * DIM + r) * nb + 2 * DIM + k];
-            JacT[imu_leng - 3 + r] += gg[2 * DIM + r];
-          }
-        }
-      }
-      for (double &h : Hess) h *= imu_coef;                           // VM:565-567
-      for (double &j : JacT) j *= imu_coef;
-      residual *= (imu_coef * 0.5);
-      st = fetch(c, c->d_full, nout, lid.data());
-      if (st) return st;
-      for (int i = 0; i < W; i++) {                                   // hess_plus VM:509-517
-        for (int r = 0; r < 6; r++) JacT[i * DIM + r] += lid[(size_t)n6 * n6 + i * 6 + r];
-        for (int j = 0; j < W; j++)
-          for (int r = 0; r < 6; r++)
-            for (int k = 0; k < 6; k++) Hess[(size_t)(i * DIM + r) * imu_leng + j * DIM + k] += lid[(size_t)(i * 6 + r) * n6 + j * 6 + k];
-      }
-      residual1 = residual + lid[(size_t)n6 * n6 + n6];
-      saved = Hess;                                                   // *hess = Hess (before gauge fixing, VM:650)
-    }
-    if (it == 0) resis_first = residual1;                             // VM:902-903
-    for (int r = 0; r < gauge; r++) for (int k = 0; k < imu_leng; k++) { Hess[(size_t)r * imu_leng + k] = 0; Hess[(size_t)k * imu_leng + r] = 0; }
-    for (int r = 0; r < gauge; r++) { Hess[(size_t)r * imu_leng + r] = 1; JacT[r] = 0; }
-    std::vector<double> A(Hess), rhs(imu_leng);
-    for (int r = 0; r < imu_leng; r++) { A[(size_t)r * imu_leng + r] += u * Hess[(size_t)r * imu_leng + r]; rhs[r] = -JacT[r]; }
-    vbh::ldlt_solve_inplace(A.data(), rhs.data(), dxi.data(), imu_leng);   // VM:659 / VM:918
-    if (gravity) for (int k = 0; k < 3; k++) xt[0].g[k] += dxi[imu_leng - 3 + k];     // VM:921 (accumulates on x_stats_temp)
-    for (int j = 0; j < W; j++) {                                     // VM:661-668 / VM:923-931
-      double E[9];
-      vbh::so3_exp(&dxi[DIM * j], E);
-      vbh::m3_mul(x[j].R, E, xt[j].R);
-      for (int k = 0; k < 3; k++) {
-        xt[j].p[k] = x[j].p[k] + dxi[DIM * j + 3 + k];
-        xt[j].v[k] = x[j].v[k] + dxi[DIM * j + 6 + k];
-        xt[j].bg[k] = x[j].bg[k] + dxi[DIM * j + 9 + k];
-        xt[j].ba[k] = x[j].ba[k] + dxi[DIM * j + 12 + k];
-        if (gravity) xt[j].g[k] = xt[0].g[k];
-      }
-    }
-    for (int j = 0; j < W - 1; j++) {                                 // IMU_PRE::update_state PI:296-303
-      for (int k = 0; k < 3; k++) {
-        fac[j].dbg_buf[k] = fac[j].dbg[k]; fac[j].dba_buf[k] = fac[j].dba[k];
-        fac[j].dbg[k] += dxi[DIM * j + 9 + k]; fac[j].dba[k] += dxi[DIM * j + 12 + k];
-      }
-    }
-    double q1 = 0;
-    for (int r = 0; r < imu_leng; r++) q1 += dxi[r] * (u * Hess[(size_t)r * imu_leng + r] * dxi[r] - JacT[r]);
-    q1 *= 0.5;
-    states_to_poses(reinterpret_cast<double *>(xt.data()), W, poses.data());
-    double *d_r = c->d_scal;
-    int st = eval_residual_dev(c, poses.data(), 0, V, d_r);           // only_residual VM:586-622 / VM:831-870
-    if (st) return st;
-    const double r_imu = imu_resid(xt);
-    double r_lid = 0;
-    st = fetch(c, d_r, 1, &r_lid);
-    if (st) return st;
-    residual2 = r_imu + r_lid;
-    double q = residual1 - residual2;
-    const double tr[5] = {residual1, residual2, u, v, q1};
-    c->trace.insert(c->trace.end(), tr, tr + 5);
-    if (q > 0) {
-      x = xt;
-      const double one_three = 1.0 / 3;
-      q = q / q1;
-      v = 2;
-      q = 1 - std::pow(2 * q - 1, 3);
-      u *= (q < one_three ? one_three : q);
-      is_calc_hess = true;
-    } else {
-      u = u * v;
-      v = 2 * v;
-      is_calc_hess = false;
-      for (int j = 0; j < W - 1; j++)
-        for (int k = 0; k < 3; k++) { fac[j].dbg[k] = fac[j].dbg_buf[k]; fac[j].dba[k] = fac[j].dba_buf[k]; }   // VM:701-705
-    }
-    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
-  }
-  std::memcpy(states, x.data(), (size_t)W * 25 * sizeof(double));
-  if (hess) std::memcpy(hess, saved.data(), saved.size() * sizeof(double));
-  if (gravity && resis2) { resis2[0] = resis_first; resis2[1] = residual2; }
-  return VBA_OK;
+  // the whole optimiser runs on the device (k_li_imu / k_li_solve / k_li_update) for every window the context accepts (2..16)
+  if (!li_device_supported(c->opt.win_size)) return VBA_ERR_UNSUPPORTED_WINDOW;
+  return li_ba_device(c, states, imus, gravity, max_iter, hess, resis2);
 }
 
 // ---------------------------------------------------------------- initialisation odometry on a point-cloud map (vba_kernels_kd.hpp)
