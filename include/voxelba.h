@@ -299,6 +299,9 @@ int vba_timing_calibration_read(vba_ctx *ctx, size_t n_bytes);
 /* Restrict the event bracketing to one kernel family (NULL / "" = all): two hipEventRecord calls per launch cost host
  * time, so the headline timed region brackets only the kernel whose roofline is reported. */
 int vba_timing_select(vba_ctx *ctx, const char *name);
+/* Bracket only every n-th launch of the selected family (n <= 1: every launch).  An event pair costs ~5 us of stream time on
+ * this runtime, more than the kernel it brackets: the headline timed region samples instead of bracketing every launch. */
+int vba_timing_sample_every(vba_ctx *ctx, int n);
 /* Records an event pair around no work under the name "null": the overhead that every bracketed launch carries. */
 int vba_timing_null_span(vba_ctx *ctx);
 int vba_timing_reset(vba_ctx *ctx);

@@ -21,6 +21,10 @@ struct LiDev {
   double ext[LI_MAX_W * 12];    // trial
   double tstamp[LI_MAX_W];
   double rimu[2];               // sum_f r^T cov^-1 r at the accepted states [0] / at the trial states [1]
+  // speculative damping candidates 1..LM_SPEC-1 of k_li_solve (see k_lm_solve_m): what a consumed candidate adds to the trial state
+  double ext_spec[LM_SPEC][LI_MAX_W * 12];   // trial v, bg, ba (the g slots are unused: gravity accumulates on the trial state, VM:921)
+  double ginc_spec[LM_SPEC][4];              // dxi.tail(3)
+  double binc_spec[LM_SPEC][LI_MAX_W * 6];   // bias increments of IMU_PRE::update_state (PI:296-303) per factor
 };
 
 __device__ __forceinline__ void li_state(const double *pose12, const double *ex12, double t, vbh::State &s) {
@@ -210,8 +214,10 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
   using LC = LdltCfg<NP>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int sb = blockIdx.x;                      // damping candidate of this workgroup (speculative damping, see k_lm_solve_m)
   // GL: L (and the staged matrix before it) in device memory — written and read by this one workgroup only, ordered by its barriers
-  double *Lst = GL ? lscratch : lds, *Tp = GL ? lds : Lst + LC::LTOT, *P = Tp + NP * LC::LS;
+  constexpr size_t LSCR = (size_t)LC::LTOT > (size_t)NMAX * (NMAX + 1) / 2 ? (size_t)LC::LTOT : (size_t)NMAX * (NMAX + 1) / 2;
+  double *Lst = GL ? lscratch + (size_t)sb * LSCR : lds, *Tp = GL ? lds : Lst + LC::LTOT, *P = Tp + NP * LC::LS;
   double *hd = P + NP * 8, *gs = hd + NMAX, *dsh = gs + NMAX, *xs = dsh + NMAX, *dxs = xs + NP, *red8 = dxs + NMAX;
   int *ord = (int *)(red8 + 32);
   const int tid = threadIdx.x;
@@ -244,13 +250,15 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
     gimu_v = gimu[tid];
     if (!copy_raw && tid < 15 * W) { const int a = tid / 15, lr = tid - 15 * a; glid_v = (lr < 6) ? red[C2::GB + 6 * a + lr] : 0.0; }
   }
-  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
-  const double u = s->u, rimu0 = li->rimu[0], rlid0 = copy_raw ? 0.0 : red[C2::RB];
-  if (stop) return;
+  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = sb == 0 ? s->pad : 0, use_spec = s->use_spec;
+  const double u0 = s->u, v0 = s->v, rimu0 = li->rimu[0], rlid0 = copy_raw ? 0.0 : red[C2::RB];
+  if (stop || use_spec) return;
+  double u = u0;
+  { double vb = v0; for (int k = 0; k < sb; k++) { u = u * vb; vb = 2 * vb; } }                         // VM:696-697, sb times
   if ((dbg & 16) && tid == 0) s->stamps[0] = t_begin;
   const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
   if (copy_raw) {                                  // multi-rank: the valid copy depends on is_calc_hess, so these loads come second
-    if (calc)
+    if (calc && sb == 0)
       for (int t = tid; t < C2::NOUT2; t += NT) raw[t] = src[t];
 #pragma unroll
     for (int q = 0; q < QL; q++) {
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
     }
     if (tid < 15 * W) { const int a = tid / 15, lr = tid - 15 * a; glid_v = (lr < 6) ? src[C2::GB + 6 * a + lr] : 0.0; }
   }
-  if (tid == 0 && calc) {
+  if (tid == 0 && calc && sb == 0) {
     const double rl = copy_raw ? src[C2::RB] : rlid0, r = coef * 0.5 * rimu0 + rl;
     s->r1 = r; if (iter0 == 0) s->resis_first = r;
     if ((dbg & 32) && iter0 < 3) { s->stamps[58 + 2 * iter0] = __double_as_longlong(rimu0); s->stamps[59 + 2 * iter0] = __double_as_longlong(rl); }
@@ -345,33 +353,47 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   if (tid < n) dxs[ord[tid]] = x;
   __syncthreads();
   // retraction VM:661-671 / 921-934 and the bias increments of IMU_PRE::update_state (PI:296-303)
+  // (candidates sb > 0 park what they would add in the *_spec buffers; k_li_update applies a candidate when it is consumed)
   double *gl = red8 + 16;
-  if (grav && tid < 3) { const double gn = li->ext[9 + tid] + dxs[n - 3 + tid]; gl[tid] = gn; }   // accumulates on x_stats_temp[0].g (VM:921)
+  if (grav && tid < 3) {
+    if (sb == 0) { const double gn = li->ext[9 + tid] + dxs[n - 3 + tid]; gl[tid] = gn; }   // accumulates on x_stats_temp[0].g (VM:921)
+    else li->ginc_spec[sb][tid] = dxs[n - 3 + tid];
+  }
   __syncthreads();
   if (tid < W) {
     double E[9];
     so3_exp_dev(dxs + 15 * tid, E);
     const double *R = s->x + 12 * tid;
-    double *Rt = s->xt + 12 * tid;
+    double *Rt = (sb == 0 ? s->xt : s->xt_spec[sb]) + 12 * tid;
+    double *et = (sb == 0 ? li->ext : li->ext_spec[sb]) + 12 * tid;
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * E[c] + R[3 * r + 1] * E[3 + c] + R[3 * r + 2] * E[6 + c];
     for (int k = 0; k < 3; k++) Rt[9 + k] = R[9 + k] + dxs[15 * tid + 3 + k];
-    for (int k = 0; k < 9; k++) li->ext[12 * tid + k] = li->ex[12 * tid + k] + dxs[15 * tid + 6 + k];
-    if (grav) for (int k = 0; k < 3; k++) li->ext[12 * tid + 9 + k] = gl[k];
+    for (int k = 0; k < 9; k++) et[k] = li->ex[12 * tid + k] + dxs[15 * tid + 6 + k];
+    if (grav && sb == 0) for (int k = 0; k < 3; k++) et[9 + k] = gl[k];
   }
   if (tid >= 64 && tid < 64 + li->F) {
     const int f = tid - 64;
-    double *m = imu + 304 * (size_t)f;               // dtime 66, dbg 67, dba 70, dbg_buf 73, dba_buf 76
-    for (int k = 0; k < 3; k++) {
-      m[73 + k] = m[67 + k]; m[76 + k] = m[70 + k];
-      m[67 + k] += dxs[15 * f + 9 + k]; m[70 + k] += dxs[15 * f + 12 + k];
+    if (sb == 0) {
+      double *m = imu + 304 * (size_t)f;               // dtime 66, dbg 67, dba 70, dbg_buf 73, dba_buf 76
+      for (int k = 0; k < 3; k++) {
+        m[73 + k] = m[67 + k]; m[76 + k] = m[70 + k];
+        m[67 + k] += dxs[15 * f + 9 + k]; m[70 + k] += dxs[15 * f + 12 + k];
+      }
+    } else {
+      for (int k = 0; k < 6; k++) li->binc_spec[sb][6 * f + k] = dxs[15 * f + 9 + k];
     }
   }
   double q = tid < n ? dxs[tid] * (u * hd[tid] * dxs[tid] - gs[tid]) : 0.0;            // VM:673
   for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
   if ((tid & 63) == 0) red8[tid >> 6] = q;
   __syncthreads();
-  if (tid == 0) { double t = 0; for (int w2 = 0; w2 < NT / 64; w2++) t += red8[w2]; s->q1 = 0.5 * t; }
+  if (tid == 0) {
+    double t = 0;
+    for (int w2 = 0; w2 < NT / 64; w2++) t += red8[w2];
+    s->q1_spec[sb] = 0.5 * t;
+    if (sb == 0) { s->q1 = 0.5 * t; s->spec_n = gridDim.x; s->spec_i = 0; }
+  }
   if (stamps && tid == 0) stamps[5] = clock64();
 }
 
@@ -403,7 +425,9 @@ __global__ __launch_bounds__(64) void k_li_update(LmDev *s, LiDev *li, double *_
   }
   r2 += rimu * (li->imu_coef * 0.5);
   const double r1 = s->r1, q1 = s->q1, u0 = s->u, v0 = s->v;
-  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter;
+  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter, spec_n = s->spec_n, spec_nx = s->spec_i + 1;
+  const bool have_spec = spec_nx < spec_n;        // a solved candidate for the damping a rejection leads to (k_li_solve)
+  const int sc = have_spec ? spec_nx : 0;
   double q = r1 - r2, u = u0, v = v0;
   const bool accept = q > 0;
   if (accept) {
@@ -418,8 +442,26 @@ __global__ __launch_bounds__(64) void k_li_update(LmDev *s, LiDev *li, double *_
     u = u * v;
     v = 2 * v;
     if (lane < F) { double *m = imu + 304 * (size_t)lane; for (int k = 0; k < 3; k++) { m[67 + k] = m[73 + k]; m[70 + k] = m[76 + k]; } }   // VM:701-705
+    if (have_spec) {
+      // what the next launch of k_li_solve would do with this (u, H, x): trial poses and v/bg/ba from the accepted state, gravity on
+      // top of the (rejected) trial value, bias increments on top of the restored ones (buffers = restored values)
+      double gn[3] = {0, 0, 0};
+      if (li->gravity) for (int k = 0; k < 3; k++) gn[k] = li->ext[9 + k] + li->ginc_spec[sc][k];
+      for (int t = lane; t < 12 * W; t += 64) {
+        s->xt[t] = s->xt_spec[sc][t];
+        const int k = t % 12;
+        if (k < 9) li->ext[t] = li->ext_spec[sc][t];
+        else if (li->gravity) li->ext[t] = gn[k - 9];
+      }
+      if (lane < F) {
+        double *m = imu + 304 * (size_t)lane;
+        for (int k = 0; k < 6; k++) m[67 + k] = m[73 + k] + li->binc_spec[sc][6 * lane + k];
+      }
+    }
   }
   if (lane != 0) return;
+  if (!accept && have_spec) { s->q1 = s->q1_spec[sc]; s->spec_i = sc; s->use_spec = 1; }
+  else { s->use_spec = 0; s->spec_n = 0; }
   li->rimu[1] = rimu;
   s->r2 = r2;
   if (ntr < mtr) {

@@ -9,6 +9,8 @@
 
 namespace vba {
 
+constexpr int LM_SPEC = 4;           // damping candidates solved per launch of the solve kernel (one workgroup each)
+
 struct LmDev {
   double x[VBA_MAX_WIN_DEV * 12];    // x_stats       (accepted poses)
   double xt[VBA_MAX_WIN_DEV * 12];   // x_stats_temp  (trial poses)
@@ -16,6 +18,10 @@ struct LmDev {
   int is_calc_hess, stop, iter, n_trace, all_accepted, last_accepted, max_trace, run_hess, run_res, pad;
   double trace[5 * 64];              // rows [r1, r2, u, v, q1]
   long long stamps[64];              // diagnostic (VBA_DEBUG_SOLVE bit 16)
+  // speculative damping (see k_lm_solve_m): trial poses / q1 for the damping values the next LM_SPEC - 1 consecutive rejections would use
+  int spec_n, spec_i, use_spec, pad2;
+  double q1_spec[LM_SPEC];
+  double xt_spec[LM_SPEC][VBA_MAX_WIN_DEV * 12];
 };
 
 __device__ __forceinline__ void so3_exp_dev(const double *w, double *R) {   // tools.hpp:51-66
@@ -45,8 +51,17 @@ __device__ __forceinline__ void so3_exp_dev(const double *w, double *R) {   // t
 // Blocked variant (vba_ldlt.hpp) for every supported window (n = 6W <= 96): trailing matrix in MFMA accumulators, panels
 // of 8 columns, two barriers per panel.  Everything the kernel reads was written by other kernels (in general on another
 // XCD, ~2 us per dependent trip), so the whole reduced system is requested up front and staged in LDS before the first branch.
+//
+// Speculative damping.  The solve is one workgroup on a 256-CU chip and the longest kernel of an iteration, and a REJECTED step
+// repeats it on the same H and x with a damping that is known in advance (u <- u v, v <- 2 v, VM:485-486).  So the launch has
+// LM_SPEC workgroups: workgroup b solves with the damping b consecutive rejections from now would use (the same f64 products the
+// update would form, so every candidate is bit-identical to the sequential solve) and parks its trial poses and q1 in
+// xt_spec[b] / q1_spec[b].  When the update rejects a step and a candidate is left it copies that candidate into xt / q1 and
+// sets use_spec; the next launch of this kernel then returns at once.  An accepted step discards the candidates.  No field a
+// workgroup reads on entry is written inside this kernel, so the workgroups need no ordering among themselves.
 template <int W>
 __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__restrict__ red, double *__restrict__ raw, int copy_raw) {
+  const int sb = blockIdx.x;
   using C2 = HessCfg2<W>;
   constexpr int n = 6 * W, NT = 256, NP = ((n + 1 + 15) / 16) * 16;
   using LC = LdltCfg<NP>;
@@ -72,14 +87,16 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
 #pragma unroll
     for (int k = 0; k < 12; k++) xr[k] = s->x[12 * tid + k];
   const long long t_begin = clock64();
-  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad;
-  const double u = s->u, r_v = copy_raw ? 0.0 : red[C2::RB];
-  if (stop) return;
-  long long *stamps = ((dbg & 16) && tid == 0) ? s->stamps : nullptr;
+  const int stop = s->stop, calc = s->is_calc_hess, iter0 = s->iter, dbg = s->pad, use_spec = s->use_spec;
+  const double u0 = s->u, v0 = s->v, r_v = copy_raw ? 0.0 : red[C2::RB];
+  if (stop || use_spec) return;
+  double u = u0;
+  { double vb = v0; for (int k = 0; k < sb; k++) { u = u * vb; vb = 2 * vb; } }                         // VM:485-486, sb times
+  long long *stamps = ((dbg & 16) && tid == 0 && sb == 0) ? s->stamps : nullptr;
   if (stamps) stamps[0] = t_begin;
   const double *__restrict__ src = (copy_raw && !calc) ? raw : red;
   if (copy_raw) {
-    if (calc)
+    if (calc && sb == 0)
       for (int t = tid; t < C2::NOUT2; t += NT) raw[t] = src[t];
 #pragma unroll
     for (int q = 0; q < QL; q++) {
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
     }
     if (tid < n) g_v = src[C2::GB + tid];
   }
-  if (tid == 0 && calc) { const double r = copy_raw ? src[C2::RB] : r_v; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
+  if (tid == 0 && calc && sb == 0) { const double r = copy_raw ? src[C2::RB] : r_v; s->r1 = r; if (iter0 == 0) s->resis_first = r; }   // VM:445, 449-450
 #pragma unroll
   for (int q = 0; q < QL; q++) {
     const int e = tid + NT * q;
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
     return (j >= n) ? ((i == j) ? 1.0 : 0.0) : a;
   };
   if (stamps) stamps[1] = clock64();
-  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem, (dbg & 16) ? s->stamps : nullptr);
+  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem, ((dbg & 16) && sb == 0) ? s->stamps : nullptr);
   if (stamps) stamps[3] = clock64();
   if (tid < n) xs[tid] = Lst[LC::lat(n, tid)];
   __syncthreads();
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
     double E[9];
     so3_exp_dev(dxs + 6 * tid, E);
     const double *R = xr;
-    double *Rt = s->xt + 12 * tid;
+    double *Rt = (sb == 0 ? s->xt : s->xt_spec[sb]) + 12 * tid;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -158,7 +175,11 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
   q = wave_sum_to_lane63(q);                                  // DPP adds (vba_kernels_factor.hpp), no LDS round trips
   if ((tid & 63) == 63) red8[tid >> 6] = q;
   __syncthreads();
-  if (tid == 0) s->q1 = 0.5 * (red8[0] + red8[1] + red8[2] + red8[3]);
+  if (tid == 0) {
+    const double q1 = 0.5 * (red8[0] + red8[1] + red8[2] + red8[3]);
+    s->q1_spec[sb] = q1;
+    if (sb == 0) { s->q1 = q1; s->spec_n = gridDim.x; s->spec_i = 0; }
+  }
   if (stamps) stamps[5] = clock64();
 }
 
@@ -172,9 +193,18 @@ __device__ const double *lm_xt(const LmDev *s) { return s->xt; }
 
 // One wave (all 64 lanes call it with the same r2).  Reads of the state come first, in one batch.
 __device__ void lm_update_apply(LmDev *s, double r2, int W) {
-  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter;
+  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter, spec_n = s->spec_n, spec_nx = s->spec_i + 1;
   const double r1 = s->r1, q1 = s->q1, u0 = s->u, v0 = s->v;
   const int lane = threadIdx.x & 63;
+  const bool have_spec = spec_nx < spec_n;                  // a candidate for the damping a rejection leads to (k_lm_solve_m)
+  const double *xs_ = s->xt_spec[have_spec ? spec_nx : 0];
+  double sp0 = 0.0, sp1 = 0.0, sp2 = 0.0;
+  if (have_spec) {
+    if (lane < 12 * W) sp0 = xs_[lane];
+    if (lane + 64 < 12 * W) sp1 = xs_[lane + 64];
+    if (lane + 128 < 12 * W) sp2 = xs_[lane + 128];
+  }
+  const double q1_nx = s->q1_spec[have_spec ? spec_nx : 0];
   double xt0 = 0.0, xt1 = 0.0, xt2 = 0.0;                 // up to 192 pose scalars = 3 per lane
   if (lane < 12 * W) xt0 = s->xt[lane];
   if (lane + 64 < 12 * W) xt1 = s->xt[lane + 64];
@@ -194,8 +224,15 @@ __device__ void lm_update_apply(LmDev *s, double r2, int W) {
   } else {                                                  // VM:484-490
     u = u * v;
     v = 2 * v;
+    if (have_spec) {                                        // the solve for this (u, H, x) has already been done
+      if (lane < 12 * W) s->xt[lane] = sp0;
+      if (lane + 64 < 12 * W) s->xt[lane + 64] = sp1;
+      if (lane + 128 < 12 * W) s->xt[lane + 128] = sp2;
+    }
   }
   if (lane != 0) return;
+  if (!accept && have_spec) { s->q1 = q1_nx; s->spec_i = spec_nx; s->use_spec = 1; }
+  else { s->use_spec = 0; s->spec_n = 0; }
   s->r2 = r2;
   if (ntr < mtr) {
     double *t = s->trace + 5 * ntr;

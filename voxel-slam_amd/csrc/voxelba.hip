@@ -78,6 +78,7 @@ struct vba_ctx {
   // timing
   bool timing = false;
   std::string timing_only;        // when non-empty only this kernel family is bracketed by events
+  int timing_every = 1; unsigned timing_ctr = 0;   // bracket every n-th launch of the selected family
   std::map<std::string, std::vector<TimedSpan>> spans;
 
   // device-resident LM state (lm_begin / lm_iterate / lm_end)
@@ -113,6 +114,8 @@ struct vba_ctx {
 
 namespace {
 
+// damping candidates per solve launch (vba_kernels_lm.hpp, "Speculative damping"); 1 = the plain sequential solve (tuning knob)
+static const int kLmSpec = getenv("VBA_LM_SPEC") ? std::min(std::max(atoi(getenv("VBA_LM_SPEC")), 1), (int)LM_SPEC) : (int)LM_SPEC;
 static const int kMaxBlocksHess = getenv("VBA_K3_BLOCKS") ? atoi(getenv("VBA_K3_BLOCKS")) : 256;   // persistent workgroups of the Hessian pass (tuning knob)
 
 int nout_of(int W) { return 36 * W * W + 6 * W + 1; }   // full layout [H | g | r]
@@ -123,12 +126,14 @@ int nout_tl(int W) {                                      // tile layout produce
 
 static inline bool span_on(vba_ctx *c, const char *name) { return c->timing && (c->timing_only.empty() || c->timing_only == name); }
 void span_begin(vba_ctx *c, const char *name, TimedSpan &s) {
+  s.a = s.b = nullptr;
   if (!span_on(c, name)) return;
+  if (c->timing_every > 1 && (c->timing_ctr++ % c->timing_every) != 0) return;   // sampled bracketing (vba_timing_sample_every)
   hipEventCreate(&s.a); hipEventCreate(&s.b);
   hipEventRecord(s.a, c->stream);
 }
 void span_end(vba_ctx *c, const char *name, TimedSpan &s) {
-  if (!span_on(c, name)) return;
+  if (!s.a) return;
   hipEventRecord(s.b, c->stream);
   c->spans[name].push_back(s);
 }
@@ -696,7 +701,7 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   TimedSpan sp{};
   span_begin(c, "solve", sp);
   switch (W) {
-#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(1), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(kLmSpec), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
     VBA_SM_CASE(2) VBA_SM_CASE(3) VBA_SM_CASE(4) VBA_SM_CASE(5) VBA_SM_CASE(6) VBA_SM_CASE(7) VBA_SM_CASE(8) VBA_SM_CASE(9) VBA_SM_CASE(10)
     VBA_SM_CASE(11) VBA_SM_CASE(12) VBA_SM_CASE(13) VBA_SM_CASE(14) VBA_SM_CASE(15) VBA_SM_CASE(16)
 #undef VBA_SM_CASE
@@ -800,13 +805,13 @@ static void launch_li_solve(vba_ctx *c, int copy_raw, int n, int gauge, int grav
   static_assert(GL || l_doubles == (size_t)LdltCfg<NP>::LTOT, "the staged triangle must fit the region of L");
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  if (GL && c->liscr_doubles < l_doubles) {
+  if (GL && c->liscr_doubles < l_doubles * LM_SPEC) {           // one region per damping candidate
     if (c->d_liscr) hipFree(c->d_liscr);
     c->d_liscr = nullptr; c->liscr_doubles = 0;
-    if (hipMalloc((void **)&c->d_liscr, l_doubles * sizeof(double)) != hipSuccess) return;    // (the launch below then fails and is reported)
-    c->liscr_doubles = l_doubles;
+    if (hipMalloc((void **)&c->d_liscr, l_doubles * LM_SPEC * sizeof(double)) != hipSuccess) return;    // (the launch below then fails and is reported)
+    c->liscr_doubles = l_doubles * LM_SPEC;
   }
-  hipLaunchKernelGGL((k_li_solve<W, NT, GL>), dim3(1), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
+  hipLaunchKernelGGL((k_li_solve<W, NT, GL>), dim3(kLmSpec), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
                      c->opt.imu_coef, c->d_liscr);
 }
 }  // extern "C++"
@@ -1581,6 +1586,7 @@ int vba_timing_null_span(vba_ctx *c) {   // an event pair around nothing: the br
   return VBA_OK;
 }
 int vba_timing_select(vba_ctx *c, const char *name) { c->timing_only = name ? name : ""; return VBA_OK; }
+int vba_timing_sample_every(vba_ctx *c, int n) { c->timing_every = n > 1 ? n : 1; c->timing_ctr = 0; return VBA_OK; }
 int vba_timing_reset(vba_ctx *c) {
   hipStreamSynchronize(c->stream);
   for (auto &kv : c->spans) for (auto &s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
