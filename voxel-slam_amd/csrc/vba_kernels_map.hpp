@@ -66,7 +66,7 @@ struct MapView {
   unsigned long long *hkeys; int *hvals; unsigned int hmask;
   // nodes
   int cap;
-  unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nfl2 /* the same before the occupancy sort */; unsigned int *nfkey; int *fhist /* [1 << W] */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
+  unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nfl2 /* the same before the occupancy sort */; unsigned int *nfkey; int *fhist /* [EXTRACT_NB_MAX] */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
   int *nfree_root, *nfree_blk;   // stacks of recycled node ids: single root nodes / bases of 8-node child blocks (map_prune)
   signed char *nlayer; signed char *nstate;
   unsigned char *f_exist, *f_sw, *f_plane, *f_touched; int *f_slide;
@@ -466,24 +466,32 @@ __global__ __launch_bounds__(256) void k_extract_count(MapView m, MapParams P, i
 // of the slots occupied, scattered) the passes fetched 2.06x the occupied slots' bytes (64-byte lines; PMC: 17.0 MB against 11.2 MB
 // algorithmic per residual pass); with equal masks adjacent a frame's occupied slots are runs and the factor is 1.04x.  The order of
 // the factors carries no meaning (push_voxel order of a recursive traversal in the reference; opt_state follows it, VM:1626).
-// Counting sort over the 2^W masks: key + histogram, exclusive scan (one workgroup), scatter.
-__global__ __launch_bounds__(256) void k_extract_key(MapView m, MapParams P, int nfac) {
+// Counting sort over the masks of the first min(W, 10) frames (<= 1024 buckets): key + histogram, exclusive scan (one workgroup),
+// scatter.  Both atomic stages aggregate in LDS first: thousands of factors share the popular masks and returning atomics on one
+// address serialise in L2 (~10 ns each) — the direct form took 24 + 20 us for 18k factors.
+constexpr int EXTRACT_NB_MAX = 1024;
+__global__ __launch_bounds__(256) void k_extract_key(MapView m, MapParams P, int nfac, int nb) {
+  __shared__ int lh[EXTRACT_NB_MAX];
+  for (int t = threadIdx.x; t < nb; t += 256) lh[t] = 0;
+  __syncthreads();
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= nfac) return;
-  const int id = m.nflist[a];
-  const size_t cp = (size_t)m.cap, W = (size_t)P.W;
-  unsigned int key = 0;
-  for (int i = 0; i < P.W; i++) key |= (m.nlc[((size_t)9 * W + P.mp[i]) * cp + id] != 0.0) ? (1u << i) : 0u;
-  m.nfkey[a] = key;
-  m.nfl2[a] = id;
-  atomicAdd(&m.fhist[key], 1);
+  if (a < nfac) {
+    const int id = m.nflist[a];
+    const size_t cp = (size_t)m.cap, W = (size_t)P.W;
+    unsigned int key = 0;
+    for (int i = 0; i < P.W && i < 10; i++) key |= (m.nlc[((size_t)9 * W + P.mp[i]) * cp + id] != 0.0) ? (1u << i) : 0u;
+    m.nfkey[a] = key;
+    m.nfl2[a] = id;
+    atomicAdd(&lh[key], 1);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nb; t += 256) { const int c = lh[t]; if (c) atomicAdd(&m.fhist[t], c); }
 }
 __global__ __launch_bounds__(1024) void k_extract_scan(MapView m, int nbuckets) {   // fhist[k] <- number of factors with a smaller mask
   __shared__ int part[1024];
-  const int tid = threadIdx.x, per = (nbuckets + 1023) / 1024, b0 = tid * per;
-  int sum = 0;
-  for (int k = 0; k < per; k++) if (b0 + k < nbuckets) sum += m.fhist[b0 + k];
-  part[tid] = sum;
+  const int tid = threadIdx.x;
+  const int c = tid < nbuckets ? m.fhist[tid] : 0;
+  part[tid] = c;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
     const int v = (tid >= off) ? part[tid - off] : 0;
@@ -491,17 +499,25 @@ __global__ __launch_bounds__(1024) void k_extract_scan(MapView m, int nbuckets) 
     part[tid] += v;
     __syncthreads();
   }
-  int run = part[tid] - sum;
-  for (int k = 0; k < per; k++)
-    if (b0 + k < nbuckets) { const int c = m.fhist[b0 + k]; m.fhist[b0 + k] = run; run += c; }
+  if (tid < nbuckets) m.fhist[tid] = part[tid] - c;
 }
-__global__ __launch_bounds__(256) void k_extract_scatter(MapView m, int nfac) {
+__global__ __launch_bounds__(256) void k_extract_scatter(MapView m, int nfac, int nb) {
+  __shared__ int lh[EXTRACT_NB_MAX];
+  for (int t = threadIdx.x; t < nb; t += 256) lh[t] = 0;
+  __syncthreads();
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= nfac) return;
-  const int id = m.nfl2[a];
-  const int pos = atomicAdd(&m.fhist[m.nfkey[a]], 1);
-  m.nflist[pos] = id;
-  m.nopt[id] = pos;                                          // opt_state  VM:1626
+  unsigned int key = 0;
+  int local = 0;
+  if (a < nfac) { key = m.nfkey[a]; local = atomicAdd(&lh[key], 1); }     // rank among this workgroup's factors with the same mask
+  __syncthreads();
+  for (int t = threadIdx.x; t < nb; t += 256) { const int c = lh[t]; if (c) lh[t] = atomicAdd(&m.fhist[t], c); }   // the workgroup's range
+  __syncthreads();
+  if (a < nfac) {
+    const int id = m.nfl2[a];
+    const int pos = lh[key] + local;
+    m.nflist[pos] = id;
+    m.nopt[id] = pos;                                        // opt_state  VM:1626
+  }
 }
 // pass 2: write the SoA factor store (push_voxel VM:139-147), frames in ring order pcrs[i] = pcrs_local[mp[i]] VM:1623-1624.
 // One thread per (factor, row of the voxel's SoA record): rows 0..10W-1 = the body clusters, then fix (10), pcr (10), coe,
@@ -1197,7 +1213,7 @@ inline int map_hash_alloc(MapStore &s, unsigned int cap, hipStream_t st, std::st
 inline int map_base(MapStore &s, hipStream_t st, std::string &err) {
   if (s.allocated) return VBA_OK;
   MAPCHK(hipMalloc((void **)&s.v.cnt, CNT_N * sizeof(int)));
-  MAPCHK(hipMalloc((void **)&s.v.fhist, ((size_t)1 << VBA_MAX_WIN) * sizeof(int)));
+  MAPCHK(hipMalloc((void **)&s.v.fhist, (size_t)EXTRACT_NB_MAX * sizeof(int)));
   MAPCHK(hipMemsetAsync(s.v.cnt, 0, CNT_N * sizeof(int), st));
   MAPCHK(hipMalloc((void **)&s.v.poses, VBA_MAX_WIN * 12 * sizeof(double)));
   MAPCHK(hipHostMalloc((void **)&s.h_cnt, CNT_N * sizeof(int) + 64, hipHostMallocDefault));
@@ -1452,11 +1468,11 @@ inline int map_extract_factors(MapStore &s, hipStream_t st, FactorView f, std::s
   const MapParams P = map_params(s);
   const int nfac = s.h_cnt[CNT_NODES] > 0 ? s.h_cnt[CNT_FACTORS] : 0;
   if (nfac > 1) {
-    const int nbuckets = 1 << s.opt.win_size;
+    const int nbuckets = 1 << (s.opt.win_size < 10 ? s.opt.win_size : 10);
     MAPCHK(hipMemsetAsync(s.v.fhist, 0, (size_t)nbuckets * sizeof(int), st));
-    hipLaunchKernelGGL(k_extract_key, dim3((nfac + 255) / 256), dim3(256), 0, st, s.v, P, nfac);
+    hipLaunchKernelGGL(k_extract_key, dim3((nfac + 255) / 256), dim3(256), 0, st, s.v, P, nfac, nbuckets);
     hipLaunchKernelGGL(k_extract_scan, dim3(1), dim3(1024), 0, st, s.v, nbuckets);
-    hipLaunchKernelGGL(k_extract_scatter, dim3((nfac + 255) / 256), dim3(256), 0, st, s.v, nfac);
+    hipLaunchKernelGGL(k_extract_scatter, dim3((nfac + 255) / 256), dim3(256), 0, st, s.v, nfac, nbuckets);
   }
   if (nfac > 0) hipLaunchKernelGGL(k_extract_write, dim3((nfac + 255) / 256, 10 * s.opt.win_size + 33), dim3(256), 0, st, s.v, P, f, nfac);
   MAPCHK(hipGetLastError());
