@@ -79,6 +79,7 @@ struct vba_ctx {
   bool timing = false;
   std::string timing_only;        // when non-empty only this kernel family is bracketed by events
   int timing_every = 1; unsigned timing_ctr = 0;   // bracket every n-th launch of the selected family
+  int lm_spec = LM_SPEC;          // damping candidates per solve launch
   std::map<std::string, std::vector<TimedSpan>> spans;
 
   // device-resident LM state (lm_begin / lm_iterate / lm_end)
@@ -114,8 +115,9 @@ struct vba_ctx {
 
 namespace {
 
-// damping candidates per solve launch (vba_kernels_lm.hpp, "Speculative damping"); 1 = the plain sequential solve (tuning knob)
-static const int kLmSpec = getenv("VBA_LM_SPEC") ? std::min(std::max(atoi(getenv("VBA_LM_SPEC")), 1), (int)LM_SPEC) : (int)LM_SPEC;
+// damping candidates per solve launch (vba_kernels_lm.hpp, "Speculative damping"); 1 = the plain sequential solve.  Read when a
+// context is created (tuning knob; tests compare the two forms bit for bit).
+static int lm_spec_from_env() { const char *e = getenv("VBA_LM_SPEC"); return e ? std::min(std::max(atoi(e), 1), (int)LM_SPEC) : (int)LM_SPEC; }
 static const int kMaxBlocksHess = getenv("VBA_K3_BLOCKS") ? atoi(getenv("VBA_K3_BLOCKS")) : 256;   // persistent workgroups of the Hessian pass (tuning knob)
 
 int nout_of(int W) { return 36 * W * W + 6 * W + 1; }   // full layout [H | g | r]
@@ -466,6 +468,7 @@ int vba_create(const vba_options *opt, vba_ctx **out) {
   } else {
     hipGetDevice(&c->device);
   }
+  c->lm_spec = lm_spec_from_env();
   if (opt->stream) { c->stream = (hipStream_t)opt->stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VBA_ERR_HIP; }
@@ -701,7 +704,7 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   TimedSpan sp{};
   span_begin(c, "solve", sp);
   switch (W) {
-#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(kLmSpec), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
+#define VBA_SM_CASE(WW) case WW: hipLaunchKernelGGL(k_lm_solve_m<WW>, dim3(c->lm_spec), dim3(256), 0, c->stream, c->d_lm, c->d_out, c->d_raw, copy_raw); break;
     VBA_SM_CASE(2) VBA_SM_CASE(3) VBA_SM_CASE(4) VBA_SM_CASE(5) VBA_SM_CASE(6) VBA_SM_CASE(7) VBA_SM_CASE(8) VBA_SM_CASE(9) VBA_SM_CASE(10)
     VBA_SM_CASE(11) VBA_SM_CASE(12) VBA_SM_CASE(13) VBA_SM_CASE(14) VBA_SM_CASE(15) VBA_SM_CASE(16)
 #undef VBA_SM_CASE
@@ -811,7 +814,7 @@ static void launch_li_solve(vba_ctx *c, int copy_raw, int n, int gauge, int grav
     if (hipMalloc((void **)&c->d_liscr, l_doubles * LM_SPEC * sizeof(double)) != hipSuccess) return;    // (the launch below then fails and is reported)
     c->liscr_doubles = l_doubles * LM_SPEC;
   }
-  hipLaunchKernelGGL((k_li_solve<W, NT, GL>), dim3(kLmSpec), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
+  hipLaunchKernelGGL((k_li_solve<W, NT, GL>), dim3(c->lm_spec), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
                      c->opt.imu_coef, c->d_liscr);
 }
 }  // extern "C++"
@@ -964,6 +967,10 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     for (int k = 0; k < 12; k++) sx[1 + k] = hl->x[12 * i + k];
     for (int k = 0; k < 12; k++) sx[13 + k] = h.ex[12 * i + k];
   }
+  // (a rejected LAST step has installed the next damping candidate, which nothing evaluated: the caller sees what the sequential loop
+  //  leaves behind, the restored increments of VM:701-705 = the buffers)
+  if (hl->use_spec)
+    for (int f = 0; f < F; f++) std::memcpy(fimg.data() + 304 * (size_t)f + 67, fimg.data() + 304 * (size_t)f + 73, 6 * sizeof(double));
   for (int f = 0; f < F; f++) std::memcpy(imus + 304 * (size_t)f + 67, fimg.data() + 304 * (size_t)f + 67, 12 * sizeof(double));   // dbg, dba, dbg_buf, dba_buf
   if (hess) {
     const double *lid = c->h_pin + o_lid;
