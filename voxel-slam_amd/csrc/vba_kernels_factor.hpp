@@ -238,13 +238,7 @@ struct ResCfg {
   static_assert(W * 12 <= NT, "one thread per pose scalar");
 };
 
-// SPLIT: the large-store form of the pass.  When the store is far larger than the chip holds in flight (V >~ 1e5) the pass is
-// throughput-bound; without the eigen-solve the kernel needs fewer registers and its workgroups live half as long, so it stops
-// after the frame sum (pcr_adds written) and k_residual_eig below finishes the voxels one per lane in full waves.  The split
-// re-reads pcr_adds (+80 B per voxel).  Measured at V = 9.9e5 (570 MB algorithmic, beyond the Infinity Cache): fused 208 us,
-// split 194 us; a persistent variant that walks the tiles with the next tile's first trip prefetched was SLOWER (205-227 us for
-// 768-2048 workgroups: three barriers per tile serialise what the dispatcher otherwise overlaps across many short workgroups).
-template <int W, int TV, bool STAMPS, bool SPLIT = false>
+template <int W, int TV, bool STAMPS>
 __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f, const double *__restrict__ poses, int head, int end,
                                                                   double *__restrict__ partial, const int *__restrict__ gate,
                                                                   long long *__restrict__ stamps) {
@@ -320,7 +314,6 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
       if (v < end) f.pcr[(size_t)k * vs + v] = a;
     }
   }
-  if (SPLIT) return;
   __syncthreads();
   if (STAMPS) st1 = clock64();
   double r = 0.0;
@@ -352,33 +345,100 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
   }
 }
 
-// Second half of the split pass: one lane per voxel, 256-thread workgroups; reads pcr_adds + coe, writes eig_values / eig_vectors
-// (VM:308-318) and one residual partial per workgroup.
-__global__ __launch_bounds__(256) void k_residual_eig(FactorView f, int head, int end, double *__restrict__ partial, const int *__restrict__ gate) {
-  __shared__ double sw[4];
-  if (gate && *gate == 0) return;            // the device-resident LM loop has stopped
-  const int v = head + blockIdx.x * 256 + threadIdx.x;
-  const size_t vs = (size_t)f.vs;
+// Voxel-per-lane form of the pass — used for LARGE stores (throughput-bound: V > kResidualVoxelPerLane in voxelba.hip) — for stores in OCCUPANCY-MASK ORDER (what the map's extraction produces, vba_kernels_map.hpp
+// k_extract_key): the 64 voxels of a wave then see (nearly) the same frames, so a lane can own a whole voxel without the wave issuing
+// the transform of frames its lanes do not have — the reason the slot-parallel form above exists.  No LDS, no barriers, no second
+// kernel: trip 1 = mask, fixed cluster, coe; trip 2 = every scalar of every frame the WAVE sees, all in flight at once (wave-uniform
+// skip of the others); the frames are added in frame order (VM:297-305, the same sums as the slot-parallel form: bit-identical);
+// eigen-solve and stores with all 64 lanes active.  One wave per workgroup; ~43 512-byte loads in flight per wave.
+// Measured on MI355X: V = 9.9e5 (570 MB algorithmic, beyond the Infinity Cache) 104 us = 0.69 of the 8 TB/s peak against 157 us
+// for the slot-parallel form (and 194-208 us before the store was ordered); V = 2.8e5: 28.5 us = 0.72 against 42.7 us; at the bench
+// window (V = 1.8e4: 288 waves, one per CU, the frames of a voxel serial in its lane) 7.8 us against 5.5 us — stores below
+// ~45k voxels keep the slot-parallel form.
+template <int W, bool STAMPS>
+__global__ __launch_bounds__(64) void k_residual_v(FactorView f, const double *__restrict__ poses, int head, int end,
+                                                   double *__restrict__ partial, const int *__restrict__ gate, long long *__restrict__ stamps) {
+  const int gate_v = gate ? *gate : 1;
+  const int lane = threadIdx.x;
+  const int v = head + blockIdx.x * 64 + lane;
+  const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
+  const int vc = v < end ? v : end - 1;
+  long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+  if (STAMPS) st0 = clock64();
+  unsigned int occm = f.occ[vc];
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = f.fix[(size_t)k * vs + vc];
+  double coe = f.coe[vc];
+  asm volatile("" : "+v"(occm), "+v"(coe), "+v"(acc[0]));       // keep the loads above the exit
+  if (gate_v == 0) return;
+  if (v >= end) occm = 0;
+  // trip 2: all frames the wave sees
+  double c[W][10];
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    const bool on = (occm >> i) & 1u;
+    if (__ballot(on) != 0ull) {                                   // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 10; k++) c[i][k] = on ? f.cl[(size_t)k * fs + (size_t)i * vs + v] : 0.0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 10; k++) c[i][k] = 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    const bool on = (occm >> i) & 1u;
+    if (__ballot(on) != 0ull) {
+      const double *R = poses + 12 * i;                           // uniform address: scalar loads
+      const double R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5], R6 = R[6], R7 = R[7], R8 = R[8];
+      const double tx = R[9], ty = R[10], tz = R[11];
+      if (on) {
+        const double pxx = c[i][0], pxy = c[i][1], pxz = c[i][2], pyy = c[i][3], pyz = c[i][4], pzz = c[i][5];
+        const double vx = c[i][6], vy = c[i][7], vz = c[i][8], n = c[i][9];
+        const double rv0 = R0 * vx + R1 * vy + R2 * vz;
+        const double rv1 = R3 * vx + R4 * vy + R5 * vz;
+        const double rv2 = R6 * vx + R7 * vy + R8 * vz;
+        const double m00 = R0 * pxx + R1 * pxy + R2 * pxz, m01 = R0 * pxy + R1 * pyy + R2 * pyz, m02 = R0 * pxz + R1 * pyz + R2 * pzz;
+        const double m10 = R3 * pxx + R4 * pxy + R5 * pxz, m11 = R3 * pxy + R4 * pyy + R5 * pyz, m12 = R3 * pxz + R4 * pyz + R5 * pzz;
+        const double m20 = R6 * pxx + R7 * pxy + R8 * pxz, m21 = R6 * pxy + R7 * pyy + R8 * pyz, m22 = R6 * pxz + R7 * pyz + R8 * pzz;
+        acc[0] += (m00 * R0 + m01 * R1 + m02 * R2) + 2.0 * rv0 * tx + n * tx * tx;
+        acc[1] += (m10 * R0 + m11 * R1 + m12 * R2) + (rv1 * tx + rv0 * ty) + n * ty * tx;
+        acc[2] += (m20 * R0 + m21 * R1 + m22 * R2) + (rv2 * tx + rv0 * tz) + n * tz * tx;
+        acc[3] += (m10 * R3 + m11 * R4 + m12 * R5) + 2.0 * rv1 * ty + n * ty * ty;
+        acc[4] += (m20 * R3 + m21 * R4 + m22 * R5) + (rv2 * ty + rv1 * tz) + n * tz * ty;
+        acc[5] += (m20 * R6 + m21 * R7 + m22 * R8) + 2.0 * rv2 * tz + n * tz * tz;
+        acc[6] += rv0 + n * tx; acc[7] += rv1 + n * ty; acc[8] += rv2 + n * tz;
+        acc[9] += n;
+      }
+    }
+  }
+  if (STAMPS) st1 = clock64();
   double r = 0.0;
   if (v < end) {
-    const double P00 = f.pcr[0 * vs + v], P01 = f.pcr[1 * vs + v], P02 = f.pcr[2 * vs + v], P11 = f.pcr[3 * vs + v], P12 = f.pcr[4 * vs + v];
-    const double P22 = f.pcr[5 * vs + v], s0 = f.pcr[6 * vs + v], s1 = f.pcr[7 * vs + v], s2 = f.pcr[8 * vs + v], Nv = f.pcr[9 * vs + v];
-    const double coe = f.coe[v];
+#pragma unroll
+    for (int k = 0; k < 10; k++) f.pcr[(size_t)k * vs + v] = acc[k];      // pcr_adds[a]  VM:319
+    const double Nv = acc[9];
     double iN = __builtin_amdgcn_rcp(Nv);
     iN = iN * (2.0 - Nv * iN);
     iN = iN * (2.0 - Nv * iN);
-    const double b0 = s0 * iN, b1 = s1 * iN, b2 = s2 * iN;
+    const double b0 = acc[6] * iN, b1 = acc[7] * iN, b2 = acc[8] * iN;
     double w0, w1, w2, V[9];
-    eig3_sym_dev(P00 * iN - b0 * b0, P01 * iN - b1 * b0, P02 * iN - b2 * b0, P11 * iN - b1 * b1, P12 * iN - b2 * b1, P22 * iN - b2 * b2, w0, w1, w2, V);
+    eig3_sym_dev(acc[0] * iN - b0 * b0, acc[1] * iN - b1 * b0, acc[2] * iN - b2 * b0, acc[3] * iN - b1 * b1, acc[4] * iN - b2 * b1,
+                 acc[5] * iN - b2 * b2, w0, w1, w2, V);
+    if (STAMPS) st2 = clock64();
     f.eigval[0 * vs + v] = w0; f.eigval[1 * vs + v] = w1; f.eigval[2 * vs + v] = w2;
 #pragma unroll
     for (int k = 0; k < 9; k++) f.eigvec[(size_t)k * vs + v] = V[k];
-    r = coe * w0;
+    r = coe * w0;                                                         // voxel_map.hpp:323
   }
   r = wave_sum_to_lane63(r);
-  if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = r;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+  if (lane == 63) partial[blockIdx.x] = r;
+  if (STAMPS && lane == 0 && blockIdx.x < 2048) {
+    st3 = clock64();
+    long long *o = stamps + (size_t)blockIdx.x * 4;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+  }
 }
 
 // out[j] = sum_b partial[b*nout + j]   (deterministic, fixed order).  256 threads = 16 outputs x 16 partial groups,

@@ -256,10 +256,12 @@ int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int 
 #ifndef VBA_K4_TV
 #define VBA_K4_TV 32        // voxels per workgroup of the residual pass (tools/ builds 16 / 64 for comparison)
 #endif
-// number of workgroups (= residual partials) of the residual pass over n voxels.  Stores beyond kResidualSplit voxels take the
-// two-kernel form (k_residual_s<..., SPLIT> + k_residual_eig): their partials come from k_residual_eig, one per 256 voxels.
-static const int kResidualSplit = 1 << 17;
-inline int residual_nb(int n) { return n > kResidualSplit ? (n + 255) / 256 : (n + VBA_K4_TV - 1) / VBA_K4_TV; }
+// number of workgroups (= residual partials) of the residual pass over n voxels: small stores (latency-bound) take the
+// slot-parallel kernel k_residual_s, large ones (throughput-bound) the voxel-per-lane kernel k_residual_v (vba_kernels_factor.hpp)
+// (measured crossover on MI355X, hesai200k_w10 scene tiled: 36.8k voxels 6.4 vs 7.1 us, 55.1k voxels 8.7 vs 7.5 us)
+static const int kResidualVoxelPerLane = getenv("VBA_K4_VPL_FROM") ? atoi(getenv("VBA_K4_VPL_FROM")) : 45000;   // tuning knob
+inline bool residual_vpl(int n) { return n > kResidualVoxelPerLane; }
+inline int residual_nb(int n) { return residual_vpl(n) ? (n + 63) / 64 : (n + VBA_K4_TV - 1) / VBA_K4_TV; }
 
 // diagnostic (VBA_K4_STAMPS=1): in-kernel clock stamps of a separate STAMPS instantiation; the production kernel holds none
 void k4_stamps_dump(vba_ctx *c, int nb, long long *d_st) {
@@ -284,21 +286,26 @@ int launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int
     if (!d_st) hipMalloc((void **)&d_st, 2048 * 4 * 8);
     hipMemsetAsync(d_st, 0, 2048 * 4 * 8, c->stream);
   }
-  const bool split = (end - head) > kResidualSplit;
-  const int nb1 = (end - head + VBA_K4_TV - 1) / VBA_K4_TV;
+  if (residual_vpl(end - head)) {
+#define VBA_RESV_CASE(WW) case WW: \
+    if (want_stamps) hipLaunchKernelGGL((k_residual_v<WW, true>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate, d_st); \
+    else hipLaunchKernelGGL((k_residual_v<WW, false>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate, (long long *)nullptr); break;
+    switch (c->opt.win_size) {
+      VBA_RESV_CASE(2) VBA_RESV_CASE(3) VBA_RESV_CASE(4) VBA_RESV_CASE(5) VBA_RESV_CASE(6) VBA_RESV_CASE(7) VBA_RESV_CASE(8) VBA_RESV_CASE(9) VBA_RESV_CASE(10)
+      VBA_RESV_CASE(11) VBA_RESV_CASE(12) VBA_RESV_CASE(13) VBA_RESV_CASE(14) VBA_RESV_CASE(15) VBA_RESV_CASE(16)
+    }
+#undef VBA_RESV_CASE
+  } else {
 #define VBA_RES_CASE(WW) case WW: { using RC = ResCfg<WW, VBA_K4_TV>; \
-    if (split) hipLaunchKernelGGL((k_residual_s<WW, VBA_K4_TV, false, true>), dim3(nb1), dim3(RC::NT), 0, c->stream, c->fv, pd, head, end, part, gate, (long long *)nullptr); \
-    else if (want_stamps) hipLaunchKernelGGL((k_residual_s<WW, VBA_K4_TV, true>), dim3(nb), dim3(RC::NT), 0, c->stream, c->fv, pd, head, end, part, gate, d_st); \
+    if (want_stamps) hipLaunchKernelGGL((k_residual_s<WW, VBA_K4_TV, true>), dim3(nb), dim3(RC::NT), 0, c->stream, c->fv, pd, head, end, part, gate, d_st); \
     else hipLaunchKernelGGL((k_residual_s<WW, VBA_K4_TV, false>), dim3(nb), dim3(RC::NT), 0, c->stream, c->fv, pd, head, end, part, gate, (long long *)nullptr); break; }
-  switch (c->opt.win_size) {
-    VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(7) VBA_RES_CASE(8) VBA_RES_CASE(9) VBA_RES_CASE(10)
-    VBA_RES_CASE(11) VBA_RES_CASE(12) VBA_RES_CASE(13) VBA_RES_CASE(14) VBA_RES_CASE(15) VBA_RES_CASE(16)
-  }
+    switch (c->opt.win_size) {
+      VBA_RES_CASE(2) VBA_RES_CASE(3) VBA_RES_CASE(4) VBA_RES_CASE(5) VBA_RES_CASE(6) VBA_RES_CASE(7) VBA_RES_CASE(8) VBA_RES_CASE(9) VBA_RES_CASE(10)
+      VBA_RES_CASE(11) VBA_RES_CASE(12) VBA_RES_CASE(13) VBA_RES_CASE(14) VBA_RES_CASE(15) VBA_RES_CASE(16)
+    }
 #undef VBA_RES_CASE
-  if (split) {
-    hipLaunchKernelGGL(k_residual_eig, dim3(nb), dim3(256), 0, c->stream, c->fv, head, end, part, gate);
   }
-  if (want_stamps && !split) k4_stamps_dump(c, nb, d_st);
+  if (want_stamps) k4_stamps_dump(c, nb, d_st);
   return nb;
 }
 
