@@ -163,7 +163,7 @@ def scaled_residual_pass(capi, torch, wl, scans, poses0, copies=56):
     gbs = by / (us * 1e-6) / 1e9
     ctx.close()
     return {"copies": copies, "voxels": V, "occupied_frames_per_voxel": occ, "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch": by,
-            "layout_extra_bytes_per_launch": V * 4 + V * 80, "layout_extra_note": "occupancy mask + pcr_adds re-read by the second kernel of the large-store form",
+            "layout_extra_bytes_per_launch": V * 4, "layout_extra_note": "4-byte occupancy mask per voxel", "kernel": "k_residual_v<%d> (one lane per voxel; stores beyond 45k voxels)" % W,
             "exceeds_2x_infinity_cache": bool(by >= 2 * 256 * 2 ** 20),
             "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
 
@@ -690,10 +690,10 @@ def main():
     if world == 1 and not args.no_scaled:
         scaled = scaled_residual_pass(capi, torch, wl, scans, poses0, copies=args.scene_copies)
         if prof is not None:
-            k4 = [k for k in prof[1]["kernels"] if k["name"].startswith("vba::k_residual_s<%d" % W)]
+            k4 = [k for k in prof[1]["kernels"] if k["name"].startswith("vba::k_residual_v<%d" % W)]   # the large-store kernel (one lane per voxel)
             if k4:
                 big = max(k4, key=lambda k: k["grid_threads"])
-                if big["grid_threads"] > 4 * 32 * W * (V_local // 32 + 1) // 4:
+                if big["grid_threads"] >= scaled["voxels"]:
                     scaled["rocprofv3_avg_launch_us"] = big["avg_ns"] / 1000.0
                     ff = prof[1].get("calibration", {}).get("fetch_bytes_per_counted_byte")
                     if "FETCH_SIZE_KB_median" in big and "WRITE_SIZE_KB_median" in big and ff:
