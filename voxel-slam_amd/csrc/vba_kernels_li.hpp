@@ -54,7 +54,8 @@ __host__ __device__ inline double li_hb_get(const double *hb, int W, int n, int 
 // ascending factor order, so the result does not depend on scheduling.  himu is COMPACT (li_hb_* below): the 3W-2 state
 // blocks, then the gravity border and corner — 7.2k doubles at W = 10 instead of the 23k of the dense matrix, because
 // the solve kernel pays ~2 us per batch of loads for data another kernel wrote.
-__global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiDev *__restrict__ li, const double *__restrict__ imu, double *__restrict__ himu,
+constexpr int LI_IMU_NT = 512;   // (256 threads: 28.6 us; the contraction phases scale with the threads, the one-lane-per-factor algebra does not)
+__global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ s, LiDev *__restrict__ li, const double *__restrict__ imu, double *__restrict__ himu,
                                                 double *__restrict__ gimu) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (s->stop || !s->is_calc_hess) return;
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
   long long *stp = ((s->pad & 64) && tid == 0) ? const_cast<long long *>(s->stamps) + 40 : nullptr;   // diagnostic
   if (stp) stp[0] = clock64();
   double *joc = lds, *cj = joc + (size_t)F * 15 * nb, *rr = cj + (size_t)F * 15 * nb, *cr = rr + F * 15, *qf = cr + F * 15, *cinv = qf + ((F + 1) & ~1);
-  for (int t = tid; t < F * 15 * nb; t += 256) joc[t] = 0.0;
-  for (int t = tid; t < F * 225; t += 256) cinv[t] = imu[304 * (size_t)(t / 225) + 79 + t % 225];
+  for (int t = tid; t < F * 15 * nb; t += LI_IMU_NT) joc[t] = 0.0;
+  for (int t = tid; t < F * 225; t += LI_IMU_NT) cinv[t] = imu[304 * (size_t)(t / 225) + 79 + t % 225];
   __syncthreads();
   if (tid < F) {
     vbh::State s1, s2;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
   if (stp) stp[1] = clock64();
   {   // cj_f = cov^-1 joc_f in 3 x 3 register tiles (6 LDS loads per 9 FMAs; one output per thread was LDS-bandwidth bound)
     const int ncb = nb / 3, ntask = F * 5 * ncb;
-    for (int t = tid; t < ntask; t += 256) {
+    for (int t = tid; t < ntask; t += LI_IMU_NT) {
       const int f = t / (5 * ncb), rem = t - f * 5 * ncb, kb = rem / ncb, cb = rem - kb * ncb;
       const double *jf = joc + (size_t)f * 15 * nb + 3 * cb, *cv = cinv + (size_t)f * 225 + 45 * kb;
       double a[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
   // state blocks in 3 x 3 register tiles: task = (block pair (a, b), tile); <= 2 factors contribute, ascending
   {
     const int npair = 3 * W - 2;
-    for (int t = tid; t < npair * 25; t += 256) {
+    for (int t = tid; t < npair * 25; t += LI_IMU_NT) {
       const int pr = t / 25, tile = t - 25 * pr, r0 = 3 * (tile / 5), c0 = 3 * (tile % 5);
       const int a = (pr + 1) / 3, b = a + ((pr + 1) % 3) - 1;
       double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void k_li_imu(const LmDev *__restrict__ s, LiD
     }
   }
   if (grav) {                                                // gravity border VM:788-795 and the 3 x 3 corner
-    for (int e = tid; e < 15 * W * 3; e += 256) {
+    for (int e = tid; e < 15 * W * 3; e += LI_IMU_NT) {
       const int R = e / 3, k = e - 3 * R, a = R / 15, r = R - 15 * a;
       double u1 = 0, u2 = 0;
       if (a >= 1) { u1 += jtj(a - 1, 15 + r, 30 + k); u2 += jtj(a - 1, 30 + k, 15 + r); }

@@ -880,7 +880,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     // the IMU factors (one workgroup) first, then the lidar Hessian pass, on the SAME stream.  A side stream for the IMU kernel
     // (fork / join events around it) was measured slower: 209 vs 196 us per iteration — the two cross-stream dependencies cost
     // more than the 28 us of the kernel they hid.
-    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(256), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
+    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(LI_IMU_NT), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
     if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);   // lidar part of divide_thread (+ all-reduce)
     if (st) { c->lm.active = false; return st; }
     TimedSpan s1{};
