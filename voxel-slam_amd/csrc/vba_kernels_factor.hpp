@@ -592,12 +592,27 @@ __device__ __forceinline__ double lm_sum_partials(const double *__restrict__ r2_
   return acc;
 }
 
+// LI-BA rides along: when `li.dev` is set the launch has ONE workgroup more than `nwg` (block 0), and that workgroup computes the IMU factors'
+// Hessian / gradient (li_imu_body, vba_kernels_li.hpp: VM:551-567) while the others do the lidar pass — the two are independent, the
+// IMU part is a single workgroup of ~28 us, and as a kernel of its own it sat in front of this pass on the stream.
+struct LiDev;
+struct LiJob { const LmDev *lm; LiDev *dev; const double *imu; double *himu, *gimu; };
+__device__ void li_imu_body(const LmDev *s, LiDev *li, const double *imu, double *himu, double *gimu, double *lds);
+
 template <int W>
 __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, const double *__restrict__ poses, int head, int end,
                                                              int ntiles, double *__restrict__ partial, const int *__restrict__ gate,
-                                                             long long *__restrict__ stamps, LmDev *lm, const double *__restrict__ k4_partial, int k4_nb) {
+                                                             long long *__restrict__ stamps, LmDev *lm, const double *__restrict__ k4_partial, int k4_nb,
+                                                             int nwg, LiJob li) {
   using C = HessCfg2<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // (every wave of this kernel holds ~300 registers, so a CU takes ONE workgroup: the IMU workgroup is block 0 — dispatched first —
+  //  and the host launches one lidar workgroup fewer than there are CUs, or it would run after them instead of beside them)
+  if (li.dev && blockIdx.x == 0) {
+    li_imu_body(li.lm, li.dev, li.imu, li.himu, li.gimu, lds);
+    return;
+  }
+  const int bid = (int)blockIdx.x - (li.dev ? 1 : 0);
   __shared__ int lm_dec[2];
   int gate_v = (gate && !lm) ? *gate : 1;     // consumed after the first tile's loads have been requested (one trip, not two)
   double lm_r2 = 0.0;
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
     poses = lm_xt(lm);
   }
   // diagnostic stamps (stamps == nullptr in production): per workgroup [start, prologue, A0, B0, A1, B1, ..., reduce, end]
-#define VBA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define VBA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 16 + (i)] = wall_clock64(); } while (0)
   VBA_STAMP(0);
   double *G = lds;                            // [NK][GS]
   double *cK = G + (size_t)C::NK * C::GS;     // [NK]
@@ -638,19 +653,19 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
 
   SlotLoad nx;
   nx.valid = false;
-  if (slot_thread && (int)blockIdx.x < ntiles) slot_load<W>(f, head + blockIdx.x * C::TV + vl, fi, end, nx);
+  if (slot_thread && bid < ntiles) slot_load<W>(f, head + bid * C::TV + vl, fi, end, nx);
   asm volatile("" : "+v"(nx.n));
   if (gate_v == 0) return;                    // uniform
   __syncthreads();
   if (lm) {
     const int run = lm_dec[0], was_stopped = lm_dec[1];
-    if (blockIdx.x == 0 && threadIdx.x < 64 && !was_stopped) lm_update_apply(lm, lm_r2, W);
+    if (bid == 0 && threadIdx.x < 64 && !was_stopped) lm_update_apply(lm, lm_r2, W);
     if (!run) return;                         // uniform: rejected step or converged -> no Hessian pass (VM:443)
   }
   VBA_STAMP(1);
   int stamp_i = 2;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = bid; tile < ntiles; tile += nwg) {
     // ---------------- phase A (registers of this tile were loaded one iteration ago)
     if (slot_thread) {
       const SlotLoad q = nx;
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
       for (int d = 0; d < 6; d++) { g[d] = g1[d]; g[C::GS + d] = g2[d]; g[2 * C::GS + d] = hh[d]; }
       if (fi == 0) { cK[3 * vl] = ck1; cK[3 * vl + 1] = ck2; cK[3 * vl + 2] = ck3; }
       // the next tile's loads fly under this tile's contraction
-      const int nt = tile + gridDim.x;
+      const int nt = tile + nwg;
       nx.valid = false;
       if (nt < ntiles) slot_load<W>(f, head + nt * C::TV + vl, fi, end, nx);
     }
@@ -780,7 +795,7 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
   VBA_STAMP(12);
 
   // ---------------- epilogue: accumulator tiles go to HBM in register order (coalesced 512 B per wave store)
-  double *out = partial + (size_t)blockIdx.x * C::NOUT2;
+  double *out = partial + (size_t)bid * C::NOUT2;
   double *Tb = lds;                                   // [NU][256] staging to combine k-splits
   double *Eb = Tb + (C::KS > 1 ? C::NU * 256 : 0);    // [28][NG8]
   if (C::KS > 1) {

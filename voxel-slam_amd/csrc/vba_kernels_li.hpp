@@ -54,17 +54,19 @@ __host__ __device__ inline double li_hb_get(const double *hb, int W, int n, int 
 // ascending factor order, so the result does not depend on scheduling.  himu is COMPACT (li_hb_* below): the 3W-2 state
 // blocks, then the gravity border and corner — 7.2k doubles at W = 10 instead of the 23k of the dense matrix, because
 // the solve kernel pays ~2 us per batch of loads for data another kernel wrote.
-constexpr int LI_IMU_NT = 512;   // (256 threads: 28.6 us; the contraction phases scale with the threads, the one-lane-per-factor algebra does not)
-__global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ s, LiDev *__restrict__ li, const double *__restrict__ imu, double *__restrict__ himu,
-                                                double *__restrict__ gimu) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+// (one workgroup of blockDim.x threads, a multiple of 64; `lds` = the launch's dynamic LDS.  Runs as the extra workgroup of the lidar
+//  Hessian launch k_hessian2 (256 threads) or as the kernel k_li_imu below)
+constexpr int LI_IMU_NT = 256;
+__device__ void li_imu_body(const LmDev *s, LiDev *li, const double *imu, double *himu, double *gimu, double *lds) {
+  const int NTH = blockDim.x;
   if (s->stop || !s->is_calc_hess) return;
   const int W = li->W, F = li->F, nb = li->nb, n = li->n, grav = li->gravity, tid = threadIdx.x;
   long long *stp = ((s->pad & 64) && tid == 0) ? const_cast<long long *>(s->stamps) + 40 : nullptr;   // diagnostic
   if (stp) stp[0] = clock64();
-  double *joc = lds, *cj = joc + (size_t)F * 15 * nb, *rr = cj + (size_t)F * 15 * nb, *cr = rr + F * 15, *qf = cr + F * 15, *cinv = qf + ((F + 1) & ~1);
-  for (int t = tid; t < F * 15 * nb; t += LI_IMU_NT) joc[t] = 0.0;
-  for (int t = tid; t < F * 225; t += LI_IMU_NT) cinv[t] = imu[304 * (size_t)(t / 225) + 79 + t % 225];
+  double *joc = lds, *cj = joc + (size_t)F * 15 * nb, *rr = cj + (size_t)F * 15 * nb, *cr = rr + F * 15, *qf = cr + F * 15;
+  // (cov^-1 is read from memory where it is needed: keeping a copy in LDS put the footprint over 80 KB at W = 10, and two workgroups
+  //  per CU — this one beside a workgroup of the lidar pass — need it under that)
+  for (int t = tid; t < F * 15 * nb; t += NTH) joc[t] = 0.0;
   __syncthreads();
   if (tid < F) {
     vbh::State s1, s2;
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ 
   if (stp) stp[1] = clock64();
   {   // cj_f = cov^-1 joc_f in 3 x 3 register tiles (6 LDS loads per 9 FMAs; one output per thread was LDS-bandwidth bound)
     const int ncb = nb / 3, ntask = F * 5 * ncb;
-    for (int t = tid; t < ntask; t += LI_IMU_NT) {
+    for (int t = tid; t < ntask; t += NTH) {
       const int f = t / (5 * ncb), rem = t - f * 5 * ncb, kb = rem / ncb, cb = rem - kb * ncb;
-      const double *jf = joc + (size_t)f * 15 * nb + 3 * cb, *cv = cinv + (size_t)f * 225 + 45 * kb;
+      const double *jf = joc + (size_t)f * 15 * nb + 3 * cb, *cv = imu + 304 * (size_t)f + 79 + 45 * kb;
       double a[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll 5
       for (int k2 = 0; k2 < 15; k2++) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ 
   }
   if (tid < F * 15) {
     const int f = tid / 15, k = tid % 15;
-    const double *ci = cinv + (size_t)f * 225 + 15 * k;
+    const double *ci = imu + 304 * (size_t)f + 79 + 15 * k;
     double a = 0;
     for (int k2 = 0; k2 < 15; k2++) a += ci[k2] * rr[15 * f + k2];
     cr[tid] = a;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ 
   // state blocks in 3 x 3 register tiles: task = (block pair (a, b), tile); <= 2 factors contribute, ascending
   {
     const int npair = 3 * W - 2;
-    for (int t = tid; t < npair * 25; t += LI_IMU_NT) {
+    for (int t = tid; t < npair * 25; t += NTH) {
       const int pr = t / 25, tile = t - 25 * pr, r0 = 3 * (tile / 5), c0 = 3 * (tile % 5);
       const int a = (pr + 1) / 3, b = a + ((pr + 1) % 3) - 1;
       double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ 
     }
   }
   if (grav) {                                                // gravity border VM:788-795 and the 3 x 3 corner
-    for (int e = tid; e < 15 * W * 3; e += LI_IMU_NT) {
+    for (int e = tid; e < 15 * W * 3; e += NTH) {
       const int R = e / 3, k = e - 3 * R, a = R / 15, r = R - 15 * a;
       double u1 = 0, u2 = 0;
       if (a >= 1) { u1 += jtj(a - 1, 15 + r, 30 + k); u2 += jtj(a - 1, 30 + k, 15 + r); }
@@ -178,6 +180,10 @@ __global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *__restrict__ 
   __syncthreads();
   if (stp) stp[3] = clock64();
   if (tid == 0) { double q = 0; for (int f = 0; f < F; f++) q += qf[f]; li->rimu[0] = q; }
+}
+__global__ __launch_bounds__(LI_IMU_NT) void k_li_imu(const LmDev *s, LiDev *li, const double *imu, double *himu, double *gimu) {
+  extern __shared__ __attribute__((aligned(16))) double lds_imu[];
+  li_imu_body(s, li, imu, himu, gimu, lds_imu);
 }
 
 // lower triangle of the assembled Hessian (VM:565-578 / 803-814), before the gauge: imu_coef * IMU part + lidar 6-blocks.

@@ -205,14 +205,18 @@ int upload_poses(vba_ctx *c, const double *poses) {
 }
 
 template <int W>
-int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out, LmDev *lm, const double *k4p, int k4nb) {
+int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, int *nblocks_out, LmDev *lm, const double *k4p, int k4nb,
+                      const LiJob &li, size_t li_lds) {
   using C = HessCfg2<W>;
   const int ntiles = (end - head + C::TV - 1) / C::TV;
-  int nb = ntiles < kMaxBlocksHess ? ntiles : kMaxBlocksHess;
+  const int maxb = li.dev ? kMaxBlocksHess - 1 : kMaxBlocksHess;      // (the IMU workgroup of LI-BA takes a CU of its own)
+  int nb = ntiles < maxb ? ntiles : maxb;
   if (nb < 1) nb = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void *)k_hessian2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    // (the IMU workgroup of LI-BA needs up to 150 KB at W = 16; a lidar-only launch asks for C::LDS_BYTES)
+    const size_t li_max = 80 * 1024;
+    hipFuncSetAttribute((const void *)k_hessian2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES > li_max ? C::LDS_BYTES : li_max));
     attr_set = true;
   }
   long long *stamps = nullptr;
@@ -223,7 +227,9 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
     hipMemsetAsync(d_st, 0, (size_t)kMaxBlocksHess * 16 * 8, c->stream);
     stamps = d_st;
   }
-  hipLaunchKernelGGL(k_hessian2<W>, dim3(nb), dim3(C::NT), C::LDS_BYTES, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate, stamps, lm, k4p, k4nb);
+  const size_t lds = (li.dev && li_lds > C::LDS_BYTES) ? li_lds : C::LDS_BYTES;
+  hipLaunchKernelGGL(k_hessian2<W>, dim3(nb + (li.dev ? 1 : 0)), dim3(C::NT), lds, c->stream, c->fv, poses_dev, head, end, ntiles, c->d_partial, gate, stamps, lm, k4p, k4nb,
+                     nb, li);
   if (want_stamps) {
     std::vector<long long> h((size_t)nb * 16);
     hipStreamSynchronize(c->stream);
@@ -243,9 +249,10 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
   return VBA_OK;
 }
 
-int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0) {
+int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0,
+                   const LiJob &li = LiJob{}, size_t li_lds = 0) {
   switch (c->opt.win_size) {
-#define VBA_H_CASE(WW) case WW: return launch_hessian2_t<WW>(c, pd, gate, head, end, nb, lm, k4p, k4nb);
+#define VBA_H_CASE(WW) case WW: return launch_hessian2_t<WW>(c, pd, gate, head, end, nb, lm, k4p, k4nb, li, li_lds);
     VBA_H_CASE(2) VBA_H_CASE(3) VBA_H_CASE(4) VBA_H_CASE(5) VBA_H_CASE(6) VBA_H_CASE(7) VBA_H_CASE(8) VBA_H_CASE(9) VBA_H_CASE(10)
     VBA_H_CASE(11) VBA_H_CASE(12) VBA_H_CASE(13) VBA_H_CASE(14) VBA_H_CASE(15) VBA_H_CASE(16)
 #undef VBA_H_CASE
@@ -336,7 +343,8 @@ int ctx_allgather(vba_ctx *c, double *buf, size_t chunk) {
 }
 
 // device passes on device-resident poses (gate == nullptr: unconditional)
-int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0) {
+int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head, int end, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0,
+                 const LiJob &li = LiJob{}, size_t li_lds = 0) {
   const int W = c->opt.win_size, nout = nout_tl(W);
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)nout * sizeof(double), c->stream));
@@ -344,7 +352,7 @@ int hessian_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head,
     int nb = 0;
     TimedSpan s1{}, s2{};
     span_begin(c, "hessian", s1);
-    int st = launch_hessian(c, poses_dev, gate, head, end, &nb, lm, k4p, k4nb);
+    int st = launch_hessian(c, poses_dev, gate, head, end, &nb, lm, k4p, k4nb, li, li_lds);
     if (st) return st;
     span_end(c, "hessian", s1);
     span_begin(c, "reduce", s2);
@@ -869,19 +877,26 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const int *run_hess = reinterpret_cast<const int *>(base + offsetof(LmDev, run_hess));
   const int *run_res = reinterpret_cast<const int *>(base + offsetof(LmDev, run_res));
   const int copy_raw = c->collective() ? 1 : 0;
-  const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16 + (size_t)F * 225) * sizeof(double);
+  const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16) * sizeof(double);
   {
     static bool attr_set = false;      // W = 10 with gravity: 88 KB
     constexpr int FM = LI_MAX_W - 1;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * FM * 15 * 33 + 2 * FM * 15 + FM + 16 + FM * 225) * sizeof(double))); attr_set = true; }
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * FM * 15 * 33 + 2 * FM * 15 + FM + 16) * sizeof(double))); attr_set = true; }
   }
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
     // the IMU factors (one workgroup) first, then the lidar Hessian pass, on the SAME stream.  A side stream for the IMU kernel
     // (fork / join events around it) was measured slower: 209 vs 196 us per iteration — the two cross-stream dependencies cost
     // more than the 28 us of the kernel they hid.
-    hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(LI_IMU_NT), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
-    if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);   // lidar part of divide_thread (+ all-reduce)
+    // (riding along needs both kinds of workgroup resident on one CU: <= 80 KB of LDS each; larger windows launch the IMU kernel first)
+    const bool lidar_now = !(copy_raw && c->lm.have_hess) && V > 0 && lds_imu <= 80 * 1024;
+    if (lidar_now) {          // the IMU workgroup rides in the lidar Hessian launch
+      const LiJob job{c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu};
+      st = hessian_pass(c, x_dev, run_hess, 0, V, nullptr, nullptr, 0, job, lds_imu);   // lidar part of divide_thread (+ all-reduce)
+    } else {
+      hipLaunchKernelGGL(k_li_imu, dim3(1), dim3(LI_IMU_NT), lds_imu, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu);
+      if (!(copy_raw && c->lm.have_hess)) st = hessian_pass(c, x_dev, run_hess, 0, V);
+    }
     if (st) { c->lm.active = false; return st; }
     TimedSpan s1{};
     span_begin(c, "solve", s1);
