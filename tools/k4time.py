@@ -1,4 +1,6 @@
-"""Average device time of the residual pass (K4) on the bench window, from hipEvents on the context's stream.
+"""Device time of the residual pass (K4) on the bench window, from hipEvents around single isolated launches minus the span of an
+empty event pair.  RELATIVE comparisons only (kernel variants, sizes): the subtraction under-reports the launch duration by 1-2 us
+("A measurement correction"); bench.py times a graph-replayed batch instead.
     python tools/k4time.py [copies]        # copies > 1: the scene tiled `copies` times (V x copies)
     VBA_LIB=build/libvoxelba_tv64.so python tools/k4time.py     # another build of the library (make -C voxel-slam_amd/csrc variants)"""
 import os, sys
