@@ -529,7 +529,10 @@ struct HessCfg2 {
   static constexpr int NC = 6 * W;
   static constexpr int NT16 = (NC + 15) / 16;
   static constexpr int NCP = 16 * NT16;
-  static constexpr int GS = (NCP % 32 == 16) ? NCP : NCP + 16;
+  // row stride of the LDS images in doubles.  ODD: the slot threads of one frame write rows 3 vl, 3 vl + 1, 3 vl + 2 — with the earlier
+  // stride = 16 (mod 32) their stores all fell on two bank groups (12-way conflicts); an odd stride spreads them, and the MFMA operand
+  // reads (4 rows x 16 consecutive doubles per wave) stay at 2-3 passes, far from binding
+  static constexpr int GS = ((NCP % 32 == 16) ? NCP : NCP + 16) + 1;
   static constexpr int NK = 3 * TV;
   static constexpr int NWV = NT / 64;
   static constexpr int NU = NT16 * (NT16 + 1) / 2;       // upper-triangle 16x16 tiles
@@ -543,7 +546,10 @@ struct HessCfg2 {
   static constexpr int NOUT2 = RB + 1;
   static constexpr int NG8 = NT / 8;
   static_assert(TV * W <= NT && TV % 8 == 0 && (NK / 4) % KS == 0 && (NU * KS) % NWV == 0, "tile shape");
-  static constexpr size_t LDS_MAIN = (size_t)NK * GS + NK + W * 12 + 8;
+  // PRESCALE: a second LDS image holds c_k * G, so the MFMA loop carries no f64 VALU multiply (f64 VALU and f64 MFMA share the issue on
+  // gfx950: one multiply per MFMA cost 21 of 95 cycles, tools/micro/mfma_lds.hip); every window except W = 3 has the LDS for it
+  static constexpr bool PRESCALE = ((size_t)2 * NK * GS + NK + W * 12 + 8) * sizeof(double) <= (size_t)150 * 1024;
+  static constexpr size_t LDS_MAIN = (size_t)NK * GS * (PRESCALE ? 2 : 1) + NK + W * 12 + 8;
   static constexpr size_t LDS_EPI = (size_t)(KS > 1 ? NU * 256 : 0) + (size_t)28 * NG8 + 8;
   static constexpr size_t LDS_BYTES = (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) * sizeof(double);
 };
@@ -633,14 +639,15 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
 #define VBA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 16 + (i)] = wall_clock64(); } while (0)
   VBA_STAMP(0);
   double *G = lds;                            // [NK][GS]
-  double *cK = G + (size_t)C::NK * C::GS;     // [NK]
+  double *GA = C::PRESCALE ? G + (size_t)C::NK * C::GS : G;   // [NK][GS] rows scaled by c_k (the A operand)
+  double *cK = GA + (size_t)C::NK * C::GS;    // [NK]
   double *sp = cK + C::NK;                    // [W][12]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   for (int t = tid; t < W * 12; t += C::NT) sp[t] = poses[t];
   constexpr int PADC = C::GS - C::NC;                               // padded columns (none at W = 8) stay zero for the whole kernel
   if constexpr (PADC > 0)
-    for (int t = tid; t < C::NK * PADC; t += C::NT) G[(size_t)(t / PADC) * C::GS + C::NC + t % PADC] = 0.0;
+    for (int t = tid; t < C::NK * PADC; t += C::NT) { G[(size_t)(t / PADC) * C::GS + C::NC + t % PADC] = 0.0; if (C::PRESCALE) GA[(size_t)(t / PADC) * C::GS + C::NC + t % PADC] = 0.0; }
 
   const int vl = tid % C::TV, fi = tid / C::TV;
   const bool slot_thread = fi < W;
@@ -742,6 +749,11 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
       double *g = G + (size_t)(3 * vl) * C::GS + 6 * fi;
 #pragma unroll
       for (int d = 0; d < 6; d++) { g[d] = g1[d]; g[C::GS + d] = g2[d]; g[2 * C::GS + d] = hh[d]; }
+      if (C::PRESCALE) {
+        double *ga = GA + (size_t)(3 * vl) * C::GS + 6 * fi;
+#pragma unroll
+        for (int d = 0; d < 6; d++) { ga[d] = g1[d] * ck1; ga[C::GS + d] = g2[d] * ck2; ga[2 * C::GS + d] = hh[d] * ck3; }
+      }
       if (fi == 0) { cK[3 * vl] = ck1; cK[3 * vl + 1] = ck2; cK[3 * vl + 2] = ck3; }
       // the next tile's loads fly under this tile's contraction
       const int nt = tile + nwg;
@@ -766,22 +778,22 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
         while (p >= C::NT16 - ta) { p -= C::NT16 - ta; ta++; }
         const int tb = ta + p;
         const int kb = ksp * C::KSTEPS * 4;
-        gap[t] = G + (size_t)(kb + kr) * C::GS + 16 * ta + cl;
+        gap[t] = GA + (size_t)(kb + kr) * C::GS + 16 * ta + cl;
         gbp[t] = G + (size_t)(kb + kr) * C::GS + 16 * tb + cl;
         ckp[t] = cK + kb + kr;
       }
       double ar[C::UPW], cr[C::UPW], br[C::UPW];
 #pragma unroll
-      for (int t = 0; t < C::UPW; t++) { ar[t] = gap[t][0]; cr[t] = ckp[t][0]; br[t] = gbp[t][0]; }
+      for (int t = 0; t < C::UPW; t++) { ar[t] = gap[t][0]; cr[t] = C::PRESCALE ? 1.0 : ckp[t][0]; br[t] = gbp[t][0]; }
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ks++) {
         double av[C::UPW], bv[C::UPW];
 #pragma unroll
-        for (int t = 0; t < C::UPW; t++) { av[t] = ar[t] * cr[t]; bv[t] = br[t]; }
+        for (int t = 0; t < C::UPW; t++) { av[t] = C::PRESCALE ? ar[t] : ar[t] * cr[t]; bv[t] = br[t]; }
         if (ks + 1 < C::KSTEPS) {
           const int k = 4 * (ks + 1);
 #pragma unroll
-          for (int t = 0; t < C::UPW; t++) { ar[t] = gap[t][(size_t)k * C::GS]; cr[t] = ckp[t][k]; br[t] = gbp[t][(size_t)k * C::GS]; }
+          for (int t = 0; t < C::UPW; t++) { ar[t] = gap[t][(size_t)k * C::GS]; if (!C::PRESCALE) cr[t] = ckp[t][k]; br[t] = gbp[t][(size_t)k * C::GS]; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
