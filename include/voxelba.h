@@ -107,6 +107,9 @@ int vba_factor_read_back(vba_ctx *ctx, double *eig_val, double *eig_vec, double 
 /* Number of occupied (voxel, frame) slots (clusters with N != 0) in the factor store — the "slots" that the
  * algorithmic-traffic figures of DESIGN.md are priced on. */
 int vba_factor_occupied_slots(vba_ctx *ctx, long long *slots);
+/* Occupancy mask of every stored voxel (bit i = frame i of the window sees it), in store order: `masks` holds vba_factor_size()
+ * entries.  After vba_map_recut the store is in non-decreasing order of the mask's low 10 bits. */
+int vba_factor_occupancy_masks(vba_ctx *ctx, unsigned int *masks);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizers — drop-in for the three LM classes.                                                  */

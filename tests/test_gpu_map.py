@@ -323,3 +323,31 @@ def test_long_session_prune_reuses_hash_slots_and_nodes(capi, oracle, synth):
     # the node storage stopped growing once the pruning set in (steady state: what a scan creates, a prune hands back)
     assert high[-1] <= high[20] + 64, (high[20], high[-1])
     _compare_leaves(ctx.dump_leaves(), om.dump_leaves())
+
+
+def test_extracted_factors_are_in_occupancy_mask_order(oracle):
+    """tras_opt on the device stores the factors in occupancy-mask order (whole memory lines per frame instead of
+    scattered slots).  The masks must be non-decreasing, agree with the oracle's factor set as a multiset, and opt_state must follow."""
+    import voxel_slam_amd  # noqa: F401
+    from voxel_slam_amd import capi, synth
+    wl = synth.CONFIGS["avia100k_w10"]
+    s = synth.make_scans(wl)
+    poses = synth.poses_flat(s["R0"], s["p0"])
+    W = wl.win_size
+    ctx = capi.Context(capi.options_from_workload(wl))
+    om = oracle.VoxelMap(wl.win_size, wl.voxel_size, wl.max_layer, wl.min_eigen_value, wl.plane_thre, wl.min_point, wl.max_points, 5)
+    for i in range(W):
+        ctx.cut_voxel(i, s["points"][i], poses[i]); om.cut_voxel(i, s["points"][i], poses[i])
+    of = oracle.Factor(W)
+    ctx.recut(W, poses, multi=False); om.recut(W, poses, of, multi=False)
+    m = ctx.factor_occupancy_masks()
+    assert len(m) == of.size() > 1000
+    assert (np.diff((m & 1023).astype(np.int64)) >= 0).all()
+    cl, _, _ = of.read_inputs()
+    mo = ((cl[:, :, 9] != 0) * (1 << np.arange(W))[None, :]).sum(1).astype(np.uint32)
+    assert np.array_equal(np.sort(m), np.sort(mo))
+    assert abs(ctx.factor_occupancy() - (cl[:, :, 9] != 0).sum() / len(mo)) < 1e-12
+    # opt_state (column 9 of the leaf dump) is a permutation of the factor indices
+    d = ctx.dump_leaves()
+    idx = d[d[:, 9] >= 0, 9].astype(int)
+    assert np.array_equal(np.sort(idx), np.arange(len(m)))

@@ -23,7 +23,7 @@ ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED_WINDOW, ERR_TOO_FEW_VOXELS, ERR_OPT_
 EXPORTS = [
     "vba_default_options", "vba_create", "vba_destroy", "vba_status_string", "vba_last_error", "vba_synchronize",
     "vba_factor_clear", "vba_factor_push_voxels", "vba_factor_size", "vba_factor_acc_evaluate2",
-    "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots",
+    "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots", "vba_factor_occupancy_masks",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
     "vba_imu_preintegrate", "vba_imu_give_evaluate",
     "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_odom_lio_state_estimation_kdtree", "vba_odom_kdtree_reset", "vba_odom_kdtree_size", "vba_odom_kdtree_points", "vba_gba_build", "vba_hba_add_edge", "vba_hba_global", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
@@ -240,6 +240,11 @@ class Context:
         n = C.c_longlong(0)
         self._chk(self.lib.vba_factor_occupied_slots(self.h, C.byref(n)))
         return n.value / max(self.size(), 1)
+
+    def factor_occupancy_masks(self):
+        m = np.zeros(self.size(), dtype=np.uint32)
+        self._chk(self.lib.vba_factor_occupancy_masks(self.h, m.ctypes.data_as(C.POINTER(C.c_uint))))
+        return m
 
     # ---- optimizers
     def last_trace(self):

@@ -619,6 +619,13 @@ int vba_factor_read_back(vba_ctx *c, double *eig_val, double *eig_vec, double *p
   return VBA_OK;
 }
 
+int vba_factor_occupancy_masks(vba_ctx *c, unsigned int *masks) {
+  if (!masks && c->nvox > 0) return VBA_ERR_BAD_ARG;
+  if (c->nvox == 0) return VBA_OK;
+  HIPCHK(c, hipMemcpyAsync(masks, c->fv.occ, (size_t)c->nvox * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VBA_OK;
+}
 int vba_factor_occupied_slots(vba_ctx *c, long long *slots) {
   if (!slots) return VBA_ERR_BAD_ARG;
   *slots = 0;
