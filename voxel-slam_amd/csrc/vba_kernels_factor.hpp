@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void k_residual_v(FactorView f, const double *_
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nb, int nout, double *__restrict__ out,
                                                         const int *__restrict__ gate) {
   __shared__ double s[256];
-  const int gate_v = gate ? *gate : 1;            // requested together with the first 16 partials (one memory trip, see k_residual_w)
+  const int gate_v = gate ? *gate : 1;            // requested together with the first 16 partials (one memory trip, see k_residual_s)
   const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int o = blockIdx.x * 16 + j, oc = o < nout ? o : nout - 1;
   double pv[16];

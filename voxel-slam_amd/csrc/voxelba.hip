@@ -217,7 +217,7 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
   static bool attr_set = false;
   if (!attr_set) {
     // (the IMU workgroup of LI-BA needs up to 150 KB at W = 16; a lidar-only launch asks for C::LDS_BYTES)
-    const size_t li_max = 80 * 1024;
+    const size_t li_max = 150 * 1024;
     hipFuncSetAttribute((const void *)k_hessian2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES > li_max ? C::LDS_BYTES : li_max));
     attr_set = true;
   }
@@ -909,11 +909,10 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   }
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
-    // the IMU factors (one workgroup) first, then the lidar Hessian pass, on the SAME stream.  A side stream for the IMU kernel
-    // (fork / join events around it) was measured slower: 209 vs 196 us per iteration — the two cross-stream dependencies cost
-    // more than the 28 us of the kernel they hid.
-    // (riding along needs both kinds of workgroup resident on one CU: <= 80 KB of LDS each; larger windows launch the IMU kernel first)
-    const bool lidar_now = !(copy_raw && c->lm.have_hess) && V > 0 && lds_imu <= 80 * 1024;
+    // The IMU factors' workgroup rides in the lidar Hessian launch as block 0 on a CU of its own (k_hessian2).  As a kernel of its own
+    // in front of the lidar pass it cost its 28 us + a kernel boundary; on a side stream (fork / join events around it) the two
+    // cross-stream dependencies cost more than they hid (209 vs 196 us per iteration).
+    const bool lidar_now = !(copy_raw && c->lm.have_hess) && V > 0 && lds_imu <= 150 * 1024;
     if (lidar_now) {          // the IMU workgroup rides in the lidar Hessian launch
       const LiJob job{c->d_lm, c->d_li, c->d_imu, c->d_himu, c->d_gimu};
       st = hessian_pass(c, x_dev, run_hess, 0, V, nullptr, nullptr, 0, job, lds_imu);   // lidar part of divide_thread (+ all-reduce)
