@@ -620,7 +620,8 @@ def main():
     graph = None
     try:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=main_stream):
+        # (thread-local capture mode: RCCL's helper threads of a multi-rank run may touch the runtime while this thread captures)
+        with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
             for _ in range(K4_BATCH):
                 ctx.lm_refresh_eigen()
     except Exception as e:      # noqa: BLE001
