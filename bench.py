@@ -538,15 +538,16 @@ def main():
     V_total = int(vt.item())
     n_points = sum(len(p) for p in scans["points"])
 
-    def run_steps(k):
+    def run_steps(k, cx=None):
+        cx = cx or ctx
         done = 0
         while done < k:
-            ctx.lm_begin(poses0, thd_num=2)
-            ctx.lm_refresh_eigen()                   # re-create the eigen state for the restart (not counted as a step)
+            cx.lm_begin(poses0, thd_num=2)
+            cx.lm_refresh_eigen()                    # re-create the eigen state for the restart (not counted as a step)
             for _ in range(min(3, k - done)):
-                ctx.lm_iterate(sync=False)
+                cx.lm_iterate(sync=False)
                 done += 1
-            ctx.lm_end(fetch=False)                  # the whole timed region is enqueued without host synchronisation
+            cx.lm_end(fetch=False)                   # the whole timed region is enqueued without host synchronisation
 
     run_steps(args.warmup)
     # timed region: only the residual pass K4 (the kernel whose roofline is reported) is bracketed by hipEvents — every
@@ -717,6 +718,28 @@ def main():
     if world == 1:
         ctx.timing_calibration_read(1 << 30)     # one launch of known size (1 GiB): calibrates FETCH_SIZE in the rocprofv3 PMC pass
 
+    # the same loop with the damping candidates switched off (VBA_LM_SPEC=1 is read when a context is created): every rejected step
+    # then runs its own solve, as the reference's loop does.  Traces are identical bit for bit (tests/test_gpu_spec.py).
+    seq = None
+    if world == 1:
+        os.environ["VBA_LM_SPEC"] = "1"
+        try:
+            ctx2 = capi.Context(opt)
+        finally:
+            os.environ.pop("VBA_LM_SPEC", None)
+        for i in range(W):
+            ctx2._chk(ctx2.lib.vba_map_cut_voxel(ctx2.h, C.c_int(i), C.c_int(dev_scans[i].shape[0]), C.c_void_p(dev_scans[i].data_ptr()), None,
+                                                 poses0[i].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(0)))
+        ctx2.recut(W, poses0, multi=False)
+        run_steps(args.warmup, ctx2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps, ctx2)
+        torch.cuda.synchronize()
+        seq = {"value": args.steps / (time.perf_counter() - t0), "unit": "iterations/s",
+               "what": "the timed loop with one damping value per solve launch (VBA_LM_SPEC=1): a rejected step runs its own solve"}
+        ctx2.close()
+
     if rank == 0:
         out = {
             "metric": "local-BA iterations/sec (200k pts, W=10)", "value": args.steps / dt, "unit": "iterations/s",
@@ -728,8 +751,12 @@ def main():
                        "parallelism": ("voxel-bucket shard x%d + RCCL all-reduce of [H|g|r] inside the library" % world) if (dist_on and backend == "nccl")
                                       else ("voxel-bucket shard x%d + all-reduce hook (%s rehearsal)" % (world, backend)) if dist_on else "single GPU",
                        "steps_note": "a step is one trip through the LM loop body VM:441-494; %d of the 3 steps of every damping_iter call are rejected "
-                                     "steps, which skip the Hessian pass exactly as VM:443 does (the CPU baseline runs the same sequence)" % rejected_per_call},
+                                     "steps, which skip the Hessian pass exactly as VM:443 does (the CPU baseline runs the same sequence); every solve launch "
+                                     "also solves the damping values of the next 3 rejections on otherwise idle CUs, and a rejected step whose damping was "
+                                     "among them installs that solution instead of solving again (same trace bit for bit; `sequential_damping` = the loop "
+                                     "without it)" % rejected_per_call},
             "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+            "sequential_damping": seq,
             "roofline": roof,
             "roofline_residual_pass_big_scene": scaled,
             "local_mapping_step": lms,
