@@ -37,3 +37,17 @@ def test_large_store_residual_pass_equals_small_store_kernel(oracle):
     f = oracle.Factor(wl.win_size); f.push_dict(fac)
     ra = big.evaluate_only_residual(poses, 5, V - 3); rc = f.evaluate_only_residual(poses, 5, V - 3)
     assert abs(ra - rc) < 1e-9 * abs(rc)      # (18k eigenvalues of ~1e-4, each good to eps x second moments ~1e-13: random-walk sum)
+
+
+def test_voxel_per_lane_kernel_for_every_window_size():
+    """k_residual_v<W> normally runs only beyond 45 000 voxels; VBA_K4_VPL_FROM=0 (read when the library is loaded, hence a child
+    process) forces it on the small stores of the LM parity tests, for every window size 2..16 and for stores that are NOT in
+    occupancy-mask order (pushed by the host)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBA_K4_VPL_FROM="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_factor.py"), "-k", "all_window_sizes or lidar_ba_damping_iter_parity or li_ba_damping_iter_parity"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
