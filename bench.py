@@ -745,9 +745,9 @@ def main():
             "metric": "local-BA iterations/sec (200k pts, W=10)", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: Hesai-32-like synthetic scans, %d pts/scan, W=%d, voxel %.2f m; %d planar voxels "
+            "config": {"workload": "%s: %s synthetic scans, %d pts/scan, W=%d, voxel %.2f m; %d planar voxels "
                                    "(%.1f occupied frames/voxel), lidar-only LM (Lidar_BA_Optimizer)"
-                                   % (wl.name, wl.n_pts, W, wl.voxel_size, V_total, occ),
+                                   % (wl.name, "Hesai-32-like" if wl.pattern == "spin32" else "Livox-Avia-like", wl.n_pts, W, wl.voxel_size, V_total, occ),
                        "parallelism": ("voxel-bucket shard x%d + RCCL all-reduce of [H|g|r] inside the library" % world) if (dist_on and backend == "nccl")
                                       else ("voxel-bucket shard x%d + all-reduce hook (%s rehearsal)" % (world, backend)) if dist_on else "single GPU",
                        "steps_note": "a step is one trip through the LM loop body VM:441-494; %d of the 3 steps of every damping_iter call are rejected "
