@@ -316,6 +316,9 @@ int vba_timing_get(vba_ctx *ctx, const char *name, double *total_us, int *count)
  * loop body VM:441-494 / VM:643-710, end copies the refined poses back (all-NULL outputs: no synchronisation). */
 int vba_lm_begin(vba_ctx *ctx, const double *poses, int thd_num);
 int vba_lm_refresh_eigen(vba_ctx *ctx); /* device-side residual pass at the begin poses (re-creates eig/pcr_add state) */
+/* Measurement aid: enqueues exactly one launch of the Hessian pass kernel (all voxels, at the begin poses, no reduction) on the
+ * context's stream.  bench.py replays a batch of them from a HIP graph between one event pair. */
+int vba_timing_launch_hessian(vba_ctx *ctx);
 int vba_lm_iterate(vba_ctx *ctx, int *accepted, int *stop); /* NULL, NULL: enqueue only (no host synchronisation) */
 int vba_lm_end(vba_ctx *ctx, double *poses, double *hess, double *resis2);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "vba_map_cut_voxel", "vba_map_pvec_update_cut_voxel", "vba_scan_var_init", "vba_scan_down_sampling_voxel", "vba_scan_down_sampling_pvec", "vba_scan_down_sampling_close", "vba_scan_undistort", "vba_odom_lio_state_estimation_kdtree", "vba_odom_kdtree_reset", "vba_odom_kdtree_size", "vba_odom_kdtree_points", "vba_gba_build", "vba_hba_add_edge", "vba_hba_global", "vba_map_cut_voxel_fix", "vba_map_recut", "vba_map_margi", "vba_map_slide", "vba_map_prune", "vba_map_reset",
     "vba_map_num_roots", "vba_map_num_slide_roots", "vba_map_stats", "vba_map_dump_leaves", "vba_map_dump_plane_var", "vba_odom_lio_state_estimation",
     "vba_set_allreduce", "vba_rccl_get_unique_id", "vba_rccl_init", "vba_set_rccl_comm", "vba_shard_owner", "vba_set_shard",
-    "vba_timing_enable", "vba_timing_calibration_read", "vba_timing_select", "vba_timing_sample_every", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
+    "vba_timing_enable", "vba_timing_calibration_read", "vba_timing_select", "vba_timing_sample_every", "vba_timing_launch_hessian", "vba_timing_null_span", "vba_timing_reset", "vba_timing_get",
     "vba_lm_begin", "vba_lm_refresh_eigen", "vba_lm_iterate", "vba_lm_end",
     "vba_io_save_pcd", "vba_io_load_pcd", "vba_io_save_pose", "vba_io_read_lidarstate",
 ]
@@ -514,6 +514,9 @@ class Context:
 
     def timing_sample_every(self, n=1):
         self.lib.vba_timing_sample_every(self.h, C.c_int(int(n)))
+
+    def timing_launch_hessian(self):
+        self._chk(self.lib.vba_timing_launch_hessian(self.h))
 
     def timing_null_spans(self, n=64):
         """Average duration in microseconds of an event pair that brackets nothing."""

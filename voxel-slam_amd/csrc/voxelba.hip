@@ -699,6 +699,16 @@ int vba_lm_refresh_eigen(vba_ctx *c) {
   return VBA_OK;
 }
 
+int vba_timing_launch_hessian(vba_ctx *c) {
+  if (!c->lm.active || c->nvox <= 0) return VBA_ERR_BAD_ARG;
+  const double *x_dev = reinterpret_cast<const double *>(reinterpret_cast<char *>(c->d_lm) + offsetof(LmDev, x));
+  int nb = 0;
+  const int st = launch_hessian(c, x_dev, nullptr, 0, c->nvox, &nb);
+  if (st) return st;
+  HIPCHK(c, hipGetLastError());
+  return VBA_OK;
+}
+
 // One trip through the loop body VM:441-494, enqueued without host synchronisation unless the caller asks for the flags.
 int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   if (!c->lm.active) return VBA_ERR_BAD_ARG;
