@@ -497,6 +497,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     opt = capi.options_from_workload(wl, stream=stream)
     opt.device = local_rank
+    if dist_on and world == 1:
+        opt.force_collective = 1          # VBA_BENCH_FORCE_DIST: the exchange step with one rank
     ctx = capi.Context(opt)
     if dist_on:
         if backend == "nccl":
@@ -745,15 +747,13 @@ def main():
     if world == 1:
         ctx.timing_calibration_read(1 << 30)     # one launch of known size (1 GiB): calibrates FETCH_SIZE in the rocprofv3 PMC pass
 
-    # the same loop with the damping candidates switched off (VBA_LM_SPEC=1 is read when a context is created): every rejected step
-    # then runs its own solve, as the reference's loop does.  Traces are identical bit for bit (tests/test_gpu_spec.py).
+    # the same loop with the damping candidates switched off (vba_options::lm_spec = 1): every rejected step then runs its own
+    # solve, as the reference's loop does.  Traces are identical bit for bit (tests/test_gpu_spec.py).
     seq = None
     if world == 1:
-        os.environ["VBA_LM_SPEC"] = "1"
-        try:
-            ctx2 = capi.Context(opt)
-        finally:
-            os.environ.pop("VBA_LM_SPEC", None)
+        opt.lm_spec = 1
+        ctx2 = capi.Context(opt)
+        opt.lm_spec = 0
         for i in range(W):
             ctx2._chk(ctx2.lib.vba_map_cut_voxel(ctx2.h, C.c_int(i), C.c_int(dev_scans[i].shape[0]), C.c_void_p(dev_scans[i].data_ptr()), None,
                                                  poses0[i].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(0)))
@@ -764,7 +764,7 @@ def main():
         run_steps(args.steps, ctx2)
         torch.cuda.synchronize()
         seq = {"value": args.steps / (time.perf_counter() - t0), "unit": "iterations/s",
-               "what": "the timed loop with one damping value per solve launch (VBA_LM_SPEC=1): a rejected step runs its own solve"}
+               "what": "the timed loop with one damping value per solve launch (vba_options::lm_spec = 1): a rejected step runs its own solve"}
         ctx2.close()
 
     if rank == 0:

@@ -50,7 +50,8 @@ enum vba_status {
   VBA_ERR_OPT_STATE = 5,       /* OctoTree::margi "Error: opt_state" exit(0), VM:1488-1492 */
   VBA_ERR_HIP = 6,
   VBA_ERR_CAPACITY = 7,
-  VBA_ERR_IO = 8               /* file missing / malformed (read_lidarstate prints "not found" and exits, VH:271-275) */
+  VBA_ERR_IO = 8,              /* file missing / malformed (read_lidarstate prints "not found" and exits, VH:271-275) */
+  VBA_ERR_UNSUPPORTED = 9      /* the in-library RCCL exchange step was asked for but librccl.so.1 cannot be resolved in this process */
 };
 
 typedef struct vba_ctx vba_ctx;
@@ -73,6 +74,11 @@ typedef struct vba_options {
   void *stream;                     /* hipStream_t to run on, NULL = the context creates its own */
   size_t max_voxels;                /* factor capacity hint (0 = grow on demand) */
   size_t max_points_per_scan;       /* map capacity hint (0 = grow on demand) */
+  /* execution knobs (no reference counterpart; 0 = default).  They replace the environment switches of earlier builds. */
+  int lm_spec;                      /* damping candidates per solve launch, 1..4 (default 4; 1 = the plain sequential solve) */
+  int force_collective;             /* != 0: take the exchange step of the sharded LM flow with ONE rank too (rehearsals) */
+  int hessian_workgroups;           /* persistent workgroups of the Hessian pass, 2..256 (default 256 = one per CU) */
+  int residual_vpl_from;            /* residual pass: stores with more voxels use the voxel-per-lane kernel (default 45000) */
 } vba_options;
 
 void vba_default_options(vba_options *opt); /* values of config/avia.yaml:26-47 */

@@ -40,12 +40,12 @@ def test_large_store_residual_pass_equals_small_store_kernel(oracle):
 
 
 def test_voxel_per_lane_kernel_for_every_window_size():
-    """k_residual_v<W> normally runs only beyond 45 000 voxels; VBA_K4_VPL_FROM=0 (read when the library is loaded, hence a child
-    process) forces it on the small stores of the LM parity tests, for every window size 2..16 and for stores that are NOT in
+    """k_residual_v<W> normally runs only beyond 45 000 voxels; vba_options::residual_vpl_from = 1 (injected into every options struct of a child
+    pytest through the ctypes binding's VBA_PY_OPTIONS hook) forces it on the small stores of the LM parity tests, for every window size 2..16 and for stores that are NOT in
     occupancy-mask order (pushed by the host)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VBA_K4_VPL_FROM="0")
+    env = dict(os.environ, VBA_PY_OPTIONS="residual_vpl_from=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_gpu_factor.py"), "-k", "all_window_sizes or lidar_ba_damping_iter_parity or li_ba_damping_iter_parity"],
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, name="room20k_w4"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     import voxel_slam_amd  # noqa: F401
     from voxel_slam_amd import synth, capi
-    wl = synth.CONFIGS["room20k_w4"]
+    wl = synth.CONFIGS[name]
     s = synth.make_scans(wl)
     W = wl.win_size
     poses = synth.poses_flat(s["R0"], s["p0"])
@@ -75,6 +75,17 @@ def test_two_rank_sharded_lm_equals_single_rank(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    files = [p.name for p in tmp_path.iterdir()]
+    assert "ok" in files, [(p.name, p.read_text()) for p in tmp_path.iterdir()]
+
+
+def test_two_rank_sharded_lm_full_size_window(tmp_path):
+    """BASELINE.json configs[3] on its workload: the 200k-point, W = 10 window (2 M points) split by voxel bucket over two ranks
+    (both on the one card, gloo as the transport of the exchange step, voxel_map.hpp:571-581): lidar LM and LI-BA equal the
+    single-rank result."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "hesai200k_w10"), nprocs=2, join=True)
     files = [p.name for p in tmp_path.iterdir()]
     assert "ok" in files, [(p.name, p.read_text()) for p in tmp_path.iterdir()]
 
@@ -134,7 +145,6 @@ def _worker_rccl(out_dir):
     single-GPU optimiser."""
     import ctypes as C
     sys.path.insert(0, ROOT)
-    os.environ["VBA_FORCE_COLLECTIVE"] = "1"           # take the exchange step although the communicator has one rank
     import voxel_slam_amd  # noqa: F401
     from voxel_slam_amd import synth, capi
     wl = synth.CONFIGS["room20k_w4"]
@@ -143,7 +153,9 @@ def _worker_rccl(out_dir):
     poses = synth.poses_flat(s["R0"], s["p0"])
 
     def run(native):
-        ctx = capi.Context(capi.options_from_workload(wl))
+        o = capi.options_from_workload(wl)
+        o.force_collective = 1 if native else 0       # take the exchange step although the communicator has one rank
+        ctx = capi.Context(o)
         if native:
             uid = C.create_string_buffer(128)
             ctx._chk(ctx.lib.vba_rccl_get_unique_id(uid))
@@ -158,7 +170,6 @@ def _worker_rccl(out_dir):
         return out, leaves
 
     a, la = run(True)
-    os.environ.pop("VBA_FORCE_COLLECTIVE")
     b, lb = run(False)
     ok = (np.abs(a["poses"] - b["poses"]).max() < 1e-9 and np.allclose(a["trace"], b["trace"], rtol=1e-8, atol=1e-12)
           and np.abs(a["hess"] - b["hess"]).max() < 1e-9 * np.abs(b["hess"]).max() and la.shape == lb.shape)

@@ -1,6 +1,6 @@
 """Speculative damping (k_lm_solve_m / k_li_solve solve the damping values of the next rejections on idle CUs; a rejected step then
 installs a parked candidate instead of solving again): the result must be BIT-IDENTICAL to the plain sequential loop
-(VBA_LM_SPEC=1), including runs of rejections longer than the number of candidates.  The Avia workload (a +-35 degree cone that
+(vba_options::lm_spec = 1), including runs of rejections longer than the number of candidates.  The Avia workload (a +-35 degree cone that
 mostly sees one wall: lidar-only BA is ill-posed) produces such runs: 3 and 6 consecutive rejections within 14 iterations."""
 import os
 import numpy as np
@@ -17,18 +17,10 @@ def mods():
 
 
 def _ctx(capi, wl, spec):
-    old = os.environ.get("VBA_LM_SPEC")
-    if spec is None:
-        os.environ.pop("VBA_LM_SPEC", None)
-    else:
-        os.environ["VBA_LM_SPEC"] = str(spec)
-    try:
-        return capi.Context(capi.options_from_workload(wl))      # the knob is read when the context is created
-    finally:
-        if old is None:
-            os.environ.pop("VBA_LM_SPEC", None)
-        else:
-            os.environ["VBA_LM_SPEC"] = old
+    o = capi.options_from_workload(wl)
+    if spec is not None:
+        o.lm_spec = spec                                          # vba_options::lm_spec (1 = the plain sequential solve)
+    return capi.Context(o)
 
 
 def _longest_reject_run(trace):

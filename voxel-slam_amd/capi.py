@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("VBA_LIB") or os.path.join(_PKG, "libvoxelba.so")   # 
 _dp = C.POINTER(C.c_double)
 
 OK = 0
-ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED_WINDOW, ERR_TOO_FEW_VOXELS, ERR_OPT_STATE, ERR_HIP, ERR_CAPACITY = range(1, 8)
+ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED_WINDOW, ERR_TOO_FEW_VOXELS, ERR_OPT_STATE, ERR_HIP, ERR_CAPACITY, ERR_IO, ERR_UNSUPPORTED = range(1, 10)
 
 EXPORTS = [
     "vba_default_options", "vba_create", "vba_destroy", "vba_status_string", "vba_last_error", "vba_synchronize",
@@ -41,6 +41,7 @@ class Options(C.Structure):
         ("min_eigen_value", C.c_double), ("plane_eigen_value_thre", C.c_double * 4), ("min_point", C.c_double * 4),
         ("imu_coef", C.c_double), ("thread_num", C.c_int), ("device", C.c_int), ("stream", C.c_void_p),
         ("max_voxels", C.c_size_t), ("max_points_per_scan", C.c_size_t),
+        ("lm_spec", C.c_int), ("force_collective", C.c_int), ("hessian_workgroups", C.c_int), ("residual_vpl_from", C.c_int),
     ]
 
 
@@ -89,6 +90,11 @@ def _p(a):
 def default_options() -> Options:
     o = Options()
     load().vba_default_options(C.byref(o))
+    # test-harness hook of THIS binding (the library itself reads no environment): "field=value,field=value" applied to every
+    # options struct this process builds, e.g. VBA_PY_OPTIONS="residual_vpl_from=1" in the child pytest of tests/test_gpu_bigstore.py
+    for kv in filter(None, os.environ.get("VBA_PY_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        setattr(o, k.strip(), type(getattr(o, k.strip()))(float(v)))
     return o
 
 

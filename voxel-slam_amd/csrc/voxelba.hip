@@ -17,7 +17,8 @@
 #include "vba_hostmath.hpp"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>     // TYPES only: the entry points are resolved at run time (rccl_api below), the library does not link librccl
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,53 @@ using namespace vba;
 
 namespace {
 struct TimedSpan { hipEvent_t a, b; };
+
+// RCCL entry points, resolved on first use: the copy the process has ALREADY loaded wins (a host program that imported torch carries
+// torch/lib/librccl.so; binding to a second build would split the communicator state), then the system librccl.so.1.  A process
+// that never asks for the in-library exchange step (vba_rccl_init / vba_set_rccl_comm / vba_rccl_get_unique_id) needs no RCCL at all.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+const RcclApi &rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void *h = nullptr;
+    if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;            // already in the process (e.g. torch's copy)
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { const char *e = dlerror(); a.why = std::string("librccl.so.1 not found: ") + (e ? e : "?"); return a; }
+    bool all = true;
+    auto get = [&](const char *name) { void *s = dlsym(h, name); if (!s) { all = false; a.why = std::string("RCCL lacks ") + name; } return s; };
+    a.GetUniqueId = (decltype(a.GetUniqueId))get("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))get("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))get("ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))get("ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))get("ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))get("ncclGetErrorString");
+    a.ok = all;
+    return a;
+  }();
+  return api;
+}
+
+// Diagnostic switches (in-kernel stamps, host-side phase timers, ablation forms) exist only in a -DVBA_DIAG build (make diag ->
+// libvoxelba_diag.so, tools/README.md); the shipped library reads no environment variable.
+inline const char *diag_env(const char *name) {
+#ifdef VBA_DIAG
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 }
 
 struct vba_ctx {
@@ -70,7 +118,9 @@ struct vba_ctx {
   vba_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   int rank = 0, n_ranks = 1;
-  bool force_collective = std::getenv("VBA_FORCE_COLLECTIVE") != nullptr;   // rehearsal: run the exchange step with one rank
+  bool force_collective = false;  // vba_options::force_collective (rehearsal: run the exchange step with one rank)
+  int max_blocks_hess = 256;      // vba_options::hessian_workgroups
+  int residual_vpl_from = 45000;  // vba_options::residual_vpl_from
   ncclComm_t comm = nullptr;      // RCCL communicator: the exchange step is issued by the library on the context's stream
   bool own_comm = false;
   bool collective_off = false;    // replica phases (bottom-layer HBA windows) run their LM loops without the exchange step
@@ -118,9 +168,9 @@ struct vba_ctx {
 namespace {
 
 // damping candidates per solve launch (vba_kernels_lm.hpp, "Speculative damping"); 1 = the plain sequential solve.  Read when a
-// context is created (tuning knob; tests compare the two forms bit for bit).
-static int lm_spec_from_env() { const char *e = getenv("VBA_LM_SPEC"); return e ? std::min(std::max(atoi(e), 1), (int)LM_SPEC) : (int)LM_SPEC; }
-static const int kMaxBlocksHess = getenv("VBA_K3_BLOCKS") ? atoi(getenv("VBA_K3_BLOCKS")) : 256;   // persistent workgroups of the Hessian pass (tuning knob)
+// context is created (vba_options::lm_spec; tests compare the two forms bit for bit).
+static const int kMaxDevices = 64;         // per-device "kernel attribute set" flags
+static const int kMaxBlocksHess = 256;     // upper bound of vba_options::hessian_workgroups (sizes the partial slab): one workgroup per CU
 
 int nout_of(int W) { return 36 * W * W + 6 * W + 1; }   // full layout [H | g | r]
 int nout_tl(int W) {                                      // tile layout produced by k_hessian2 (HessCfg2<W>::NOUT2)
@@ -211,18 +261,18 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
                       const LiJob &li, size_t li_lds) {
   using C = HessCfg2<W>;
   const int ntiles = (end - head + C::TV - 1) / C::TV;
-  const int maxb = li.dev ? kMaxBlocksHess - 1 : kMaxBlocksHess;      // (the IMU workgroup of LI-BA takes a CU of its own)
+  const int maxb = li.dev ? c->max_blocks_hess - 1 : c->max_blocks_hess;      // (the IMU workgroup of LI-BA takes a CU of its own)
   int nb = ntiles < maxb ? ntiles : maxb;
   if (nb < 1) nb = 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {false};      // the attribute is per DEVICE (a process may hold contexts on several)
+  if (!attr_set[c->device % kMaxDevices]) {
     // (the IMU workgroup of LI-BA needs up to 150 KB at W = 16; a lidar-only launch asks for C::LDS_BYTES)
     const size_t li_max = 150 * 1024;
     hipFuncSetAttribute((const void *)k_hessian2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES > li_max ? C::LDS_BYTES : li_max));
-    attr_set = true;
+    attr_set[c->device % kMaxDevices] = true;
   }
   long long *stamps = nullptr;
-  static const bool want_stamps = getenv("VBA_K3_STAMPS") != nullptr;     // diagnostic build switch, off in production
+  static const bool want_stamps = diag_env("VBA_K3_STAMPS") != nullptr;     // -DVBA_DIAG builds only
   if (want_stamps) {
     static long long *d_st = nullptr;
     if (!d_st) hipMalloc((void **)&d_st, (size_t)kMaxBlocksHess * 16 * 8);
@@ -268,9 +318,9 @@ int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int 
 // number of workgroups (= residual partials) of the residual pass over n voxels: small stores (latency-bound) take the
 // slot-parallel kernel k_residual_s, large ones (throughput-bound) the voxel-per-lane kernel k_residual_v (vba_kernels_factor.hpp)
 // (measured crossover on MI355X, hesai200k_w10 scene tiled: 36.8k voxels 6.4 vs 7.1 us, 55.1k voxels 8.7 vs 7.5 us)
-static const int kResidualVoxelPerLane = getenv("VBA_K4_VPL_FROM") ? atoi(getenv("VBA_K4_VPL_FROM")) : 45000;   // tuning knob
-inline bool residual_vpl(int n) { return n > kResidualVoxelPerLane; }
-inline int residual_nb(int n) { return residual_vpl(n) ? (n + 63) / 64 : (n + VBA_K4_TV - 1) / VBA_K4_TV; }
+// (the crossover is vba_options::residual_vpl_from, default 45000)
+inline bool residual_vpl(const vba_ctx *c, int n) { return n > c->residual_vpl_from; }
+inline int residual_nb(const vba_ctx *c, int n) { return residual_vpl(c, n) ? (n + 63) / 64 : (n + VBA_K4_TV - 1) / VBA_K4_TV; }
 
 // diagnostic (VBA_K4_STAMPS=1): in-kernel clock stamps of a separate STAMPS instantiation; the production kernel holds none
 void k4_stamps_dump(vba_ctx *c, int nb, long long *d_st) {
@@ -288,14 +338,14 @@ void k4_stamps_dump(vba_ctx *c, int nb, long long *d_st) {
 // residual pass over voxels [head, end) (end > head); partials (one per workgroup) go to dst or d_partial; returns their number
 int launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int end, double *dst = nullptr) {
   double *part = dst ? dst : c->d_partial;
-  const int nb = residual_nb(end - head);
-  static const bool want_stamps = getenv("VBA_K4_STAMPS") != nullptr;
+  const int nb = residual_nb(c, end - head);
+  static const bool want_stamps = diag_env("VBA_K4_STAMPS") != nullptr;
   static long long *d_st = nullptr;
   if (want_stamps) {
     if (!d_st) hipMalloc((void **)&d_st, 2048 * 4 * 8);
     hipMemsetAsync(d_st, 0, 2048 * 4 * 8, c->stream);
   }
-  if (residual_vpl(end - head)) {
+  if (residual_vpl(c, end - head)) {
 #define VBA_RESV_CASE(WW) case WW: \
     if (want_stamps) hipLaunchKernelGGL((k_residual_v<WW, true>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate, d_st); \
     else hipLaunchKernelGGL((k_residual_v<WW, false>), dim3(nb), dim3(64), 0, c->stream, c->fv, pd, head, end, part, gate, (long long *)nullptr); break;
@@ -322,8 +372,9 @@ int launch_residual(vba_ctx *c, const double *pd, const int *gate, int head, int
 // communicator (vba_rccl_init / vba_set_rccl_comm), else the host program's hook (gloo rehearsals on the CPU side of tests).
 int ctx_allreduce(vba_ctx *c, double *buf, size_t n) {
   if (c->comm) {
-    const ncclResult_t r = ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, c->stream);
-    if (r != ncclSuccess) { c->set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return VBA_ERR_HIP; }
+    const RcclApi &R = rccl_api();
+    const ncclResult_t r = R.AllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) { c->set_error(std::string("ncclAllReduce: ") + R.GetErrorString(r)); return VBA_ERR_HIP; }
     return VBA_OK;
   }
   if (!c->allreduce) { c->set_error("no collective configured"); return VBA_ERR_BAD_ARG; }
@@ -335,8 +386,9 @@ int ctx_allreduce(vba_ctx *c, double *buf, size_t n) {
 int ctx_allgather(vba_ctx *c, double *buf, size_t chunk) {
   if (chunk == 0) return VBA_OK;
   if (c->comm) {
-    const ncclResult_t r = ncclAllGather(buf + (size_t)c->rank * chunk, buf, chunk, ncclDouble, c->comm, c->stream);
-    if (r != ncclSuccess) { c->set_error(std::string("ncclAllGather: ") + ncclGetErrorString(r)); return VBA_ERR_HIP; }
+    const RcclApi &R = rccl_api();
+    const ncclResult_t r = R.AllGather(buf + (size_t)c->rank * chunk, buf, chunk, ncclDouble, c->comm, c->stream);
+    if (r != ncclSuccess) { c->set_error(std::string("ncclAllGather: ") + R.GetErrorString(r)); return VBA_ERR_HIP; }
     return VBA_OK;
   }
   for (int r = 0; r < c->n_ranks; r++)
@@ -373,7 +425,7 @@ int residual_pass(vba_ctx *c, const double *poses_dev, const int *gate, int head
   if (end <= head) {
     HIPCHK(c, hipMemsetAsync(d_scalar_out, 0, sizeof(double), c->stream));
   } else {
-    const int nb = residual_nb(end - head);
+    const int nb = residual_nb(c, end - head);
     if ((size_t)nb > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
     TimedSpan s1{}, s2{};
     span_begin(c, "residual", s1);
@@ -467,6 +519,7 @@ const char *vba_status_string(int s) {
     case VBA_ERR_HIP: return "HIP runtime error";
     case VBA_ERR_CAPACITY: return "capacity exceeded";
     case VBA_ERR_IO: return "file missing or malformed";
+    case VBA_ERR_UNSUPPORTED: return "not available in this process (RCCL could not be resolved)";
     default: return "unknown";
   }
 }
@@ -485,7 +538,11 @@ int vba_create(const vba_options *opt, vba_ctx **out) {
   } else {
     hipGetDevice(&c->device);
   }
-  c->lm_spec = lm_spec_from_env();
+  c->lm_spec = opt->lm_spec > 0 ? std::min(opt->lm_spec, (int)LM_SPEC) : (int)LM_SPEC;
+  c->force_collective = opt->force_collective != 0;
+  c->max_blocks_hess = opt->hessian_workgroups > 0 ? std::min(opt->hessian_workgroups, kMaxBlocksHess) : kMaxBlocksHess;
+  if (c->max_blocks_hess < 2) c->max_blocks_hess = 2;      // (LI-BA gives one workgroup's CU to the IMU factors)
+  c->residual_vpl_from = opt->residual_vpl_from > 0 ? opt->residual_vpl_from : 45000;
   if (opt->stream) { c->stream = (hipStream_t)opt->stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VBA_ERR_HIP; }
@@ -510,7 +567,7 @@ void vba_destroy(vba_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  if (c->comm && c->own_comm) ncclCommDestroy(c->comm);
+  if (c->comm && c->own_comm) rccl_api().CommDestroy(c->comm);      // (a communicator exists only if the API resolved)
   map_free(c->map);
   c->gba.free_all();
   c->big.release();
@@ -659,7 +716,7 @@ int vba_lm_begin(vba_ctx *c, const double *poses, int thd_num) {
   h->u = 0.01; h->v = 2;                                        // VM:427
   h->is_calc_hess = 1; h->stop = 0; h->iter = 0; h->n_trace = 0; h->all_accepted = 1; h->last_accepted = 0; h->max_trace = 64;
   h->run_hess = 1; h->run_res = 1;
-  { const char *e = getenv("VBA_DEBUG_SOLVE"); h->pad = e ? atoi(e) : 0; }   // timing ablation knob (0 in production)
+  { const char *e = diag_env("VBA_DEBUG_SOLVE"); h->pad = e ? atoi(e) : 0; }   // ablation / stamp mask of -DVBA_DIAG builds (0 otherwise)
   HIPCHK(c, hipMemcpyAsync(c->d_lm, h, sizeof(LmDev), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->lm_up_ev[slot], c->stream));
   c->lm.active = true; c->lm.thd_num = thd_num; c->lm.have_hess = false; c->lm.pending_update = false;
@@ -690,7 +747,7 @@ int vba_lm_refresh_eigen(vba_ctx *c) {
   const double *x_dev = reinterpret_cast<const double *>(reinterpret_cast<char *>(c->d_lm) + offsetof(LmDev, x));
   if (c->nvox <= 0) return VBA_OK;
   // only the pass' side effect is wanted (eig_values / eig_vectors / pcr_adds at the begin poses): its partials are not summed
-  if ((size_t)residual_nb(c->nvox) > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
+  if ((size_t)residual_nb(c, c->nvox) > c->partial_doubles) { c->set_error("partial buffer too small"); return VBA_ERR_CAPACITY; }
   TimedSpan s1{};
   span_begin(c, "residual", s1);
   launch_residual(c, x_dev, nullptr, 0, c->nvox);
@@ -725,7 +782,7 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
   // iteration's Hessian; on a reject the solve keeps using its saved copy (`raw`), exactly as VM:443 skips divide_thread.
   const int copy_raw = c->collective() ? 1 : 0;
   int st = VBA_OK;
-  static const bool no_fuse = getenv("VBA_NO_FUSED_UPDATE") != nullptr;   // diagnostic: accept/reject always as its own kernel
+  static const bool no_fuse = diag_env("VBA_NO_FUSED_UPDATE") != nullptr;   // diagnostic: accept/reject always as its own kernel
   if (!(copy_raw && c->lm.have_hess)) {
     if (c->lm.pending_update) {               // the previous iteration's accept/reject rides in this pass (runs on xt after an accepted step)
       st = hessian_pass(c, x_dev, run_hess, 0, V, c->d_lm, c->d_k4part, c->lm.k4_nb);
@@ -753,7 +810,7 @@ int vba_lm_iterate(vba_ctx *c, int *accepted, int *stop) {
     c->lm.have_hess = true;
     hipLaunchKernelGGL(k_lm_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_out + (nout_tl(W) - 1), 0, W);
   } else {
-    const int nb = residual_nb(V);
+    const int nb = residual_nb(c, V);
     if (nb > c->k4part_cap) {
       if (c->d_k4part) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_k4part); c->d_k4part = nullptr; }
       const int cap = nb > 65536 ? 2 * nb : 65536;
@@ -834,29 +891,31 @@ int vba_last_lm_trace(vba_ctx *c, double *rows, int max_rows) {
 // ---------------------------------------------------------------- LI_BA_Optimizer / LI_BA_OptimizerGravity on the device
 extern "C++" {
 template <int W, int NT = (W > 10 ? 1024 : 512)>
-static void launch_li_solve(vba_ctx *c, int copy_raw, int n, int gauge, int grav) {
+static int launch_li_solve(vba_ctx *c, int copy_raw, int n, int gauge, int grav) {
   constexpr int NMAX = 15 * W + 3, NP = ((NMAX + 1 + 15) / 16) * 16;
   constexpr bool GL = W > 10;                    // L of the 15 W + 3 system exceeds the LDS: it lives in c->d_liscr
   constexpr size_t l_doubles = (size_t)LdltCfg<NP>::LTOT > (size_t)NMAX * (NMAX + 1) / 2 ? (size_t)LdltCfg<NP>::LTOT : (size_t)NMAX * (NMAX + 1) / 2;
   constexpr size_t lds = ((GL ? (size_t)LdltCfg<NP>::DOUBLES - LdltCfg<NP>::LTOT : (size_t)LdltCfg<NP>::DOUBLES) + 4 * NMAX + NP + 32) * 8 + (size_t)NMAX * 4 + 64;
   static_assert(GL || l_doubles == (size_t)LdltCfg<NP>::LTOT, "the staged triangle must fit the region of L");
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void *)k_li_solve<W, NT, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  if (GL && c->liscr_doubles < l_doubles * LM_SPEC) {           // one region per damping candidate
+  static bool attr_set[kMaxDevices] = {false};
+  if (!attr_set[c->device % kMaxDevices]) { hipFuncSetAttribute((const void *)k_li_solve<W, NT, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[c->device % kMaxDevices] = true; }
+  if (GL && c->liscr_doubles < l_doubles * LM_SPEC) {           // one region per damping candidate; W is fixed per context, so this runs once
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_liscr) hipFree(c->d_liscr);
     c->d_liscr = nullptr; c->liscr_doubles = 0;
-    if (hipMalloc((void **)&c->d_liscr, l_doubles * LM_SPEC * sizeof(double)) != hipSuccess) return;    // (the launch below then fails and is reported)
+    HIPCHK(c, hipMalloc((void **)&c->d_liscr, l_doubles * LM_SPEC * sizeof(double)));
     c->liscr_doubles = l_doubles * LM_SPEC;
   }
   hipLaunchKernelGGL((k_li_solve<W, NT, GL>), dim3(c->lm_spec), dim3(NT), lds, c->stream, c->d_lm, c->d_li, c->d_out, c->d_raw, copy_raw, c->d_himu, c->d_gimu, c->d_imu, n, gauge, grav,
                      c->opt.imu_coef, c->d_liscr);
+  return VBA_OK;
 }
 }  // extern "C++"
 
 static bool li_device_supported(int W) { return W >= 2 && W <= LI_MAX_W; }
 
 static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, int max_iter, double *hess, double *resis2) {
-  static const bool want_times = getenv("VBA_LI_TIMES") != nullptr;   // diagnostic: host-side phases of one call
+  static const bool want_times = diag_env("VBA_LI_TIMES") != nullptr;   // diagnostic: host-side phases of one call
   const auto t_0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   const int W = c->opt.win_size, V = c->nvox, DIM = VBA_DIM, F = W - 1;
@@ -913,9 +972,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
   const int copy_raw = c->collective() ? 1 : 0;
   const size_t lds_imu = ((size_t)2 * F * 15 * nb + 2 * F * 15 + F + 16) * sizeof(double);
   {
-    static bool attr_set = false;      // W = 10 with gravity: 88 KB
+    static bool attr_set[kMaxDevices] = {false};      // W = 10 with gravity: 88 KB
     constexpr int FM = LI_MAX_W - 1;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * FM * 15 * 33 + 2 * FM * 15 + FM + 16) * sizeof(double))); attr_set = true; }
+    if (!attr_set[c->device % kMaxDevices]) { hipFuncSetAttribute((const void *)k_li_imu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * FM * 15 * 33 + 2 * FM * 15 + FM + 16) * sizeof(double))); attr_set[c->device % kMaxDevices] = true; }
   }
   const double t_up = since(t_0);
   for (int it = 0; it < max_iter; it++) {
@@ -934,28 +993,29 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     TimedSpan s1{};
     span_begin(c, "solve", s1);
     switch (W) {
-      case 2: launch_li_solve<2>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 3: launch_li_solve<3>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 4: launch_li_solve<4>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 5: launch_li_solve<5>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 6: launch_li_solve<6>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 7: launch_li_solve<7>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 9: launch_li_solve<9>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 8: launch_li_solve<8>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 2: st = launch_li_solve<2>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 3: st = launch_li_solve<3>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 4: st = launch_li_solve<4>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 5: st = launch_li_solve<5>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 6: st = launch_li_solve<6>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 7: st = launch_li_solve<7>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 9: st = launch_li_solve<9>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 8: st = launch_li_solve<8>(c, copy_raw, n, h.gauge, h.gravity); break;
       case 10: {
-        static const int nt = getenv("VBA_LI_NT") ? atoi(getenv("VBA_LI_NT")) : 512;      // tuning knob
-        if (nt == 256) launch_li_solve<10, 256>(c, copy_raw, n, h.gauge, h.gravity); else if (nt == 1024) launch_li_solve<10, 1024>(c, copy_raw, n, h.gauge, h.gravity); else launch_li_solve<10, 512>(c, copy_raw, n, h.gauge, h.gravity);
+        static const int nt = diag_env("VBA_LI_NT") ? atoi(diag_env("VBA_LI_NT")) : 512;      // -DVBA_DIAG builds only
+        if (nt == 256) st = launch_li_solve<10, 256>(c, copy_raw, n, h.gauge, h.gravity); else if (nt == 1024) st = launch_li_solve<10, 1024>(c, copy_raw, n, h.gauge, h.gravity); else st = launch_li_solve<10, 512>(c, copy_raw, n, h.gauge, h.gravity);
         break;
       }
-      case 11: launch_li_solve<11>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 12: launch_li_solve<12>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 13: launch_li_solve<13>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 14: launch_li_solve<14>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 15: launch_li_solve<15>(c, copy_raw, n, h.gauge, h.gravity); break;
-      case 16: launch_li_solve<16>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 11: st = launch_li_solve<11>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 12: st = launch_li_solve<12>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 13: st = launch_li_solve<13>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 14: st = launch_li_solve<14>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 15: st = launch_li_solve<15>(c, copy_raw, n, h.gauge, h.gravity); break;
+      case 16: st = launch_li_solve<16>(c, copy_raw, n, h.gauge, h.gravity); break;
       default: c->lm.active = false; return VBA_ERR_UNSUPPORTED_WINDOW;
     }
     span_end(c, "solve", s1);
+    if (st) { c->lm.active = false; return st; }                     // (scratch allocation of the W > 10 solve failed: nothing was launched)
     if (copy_raw) {                                                   // one collective per iteration (see vba_lm_iterate)
       if (V > 0) launch_residual(c, xt_dev, run_res, 0, V);
       st = hessian_pass(c, xt_dev, run_res, 0, V);
@@ -967,7 +1027,7 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
       if (st) { c->lm.active = false; return st; }
       hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_scal, 0);
     } else {
-      const int nbk = residual_nb(V);
+      const int nbk = residual_nb(c, V);
       TimedSpan s2{};
       span_begin(c, "residual", s2);
       launch_residual(c, xt_dev, run_res, 0, V);
@@ -1309,7 +1369,7 @@ int vba_hba_add_edge(vba_ctx *c, int wdsize, const int *offsets, const double *p
   const int W = wdsize, n6 = 6 * W, n = offsets[W];
   *n_edges = 0;
   if (n_log) *n_log = 0;
-  static const bool want_times = getenv("VBA_HBA_TIMES") != nullptr;      // diagnostic: wall-clock split of the call on stderr
+  static const bool want_times = diag_env("VBA_HBA_TIMES") != nullptr;      // diagnostic: wall-clock split of the call on stderr
   double t_ph[5] = {0, 0, 0, 0, 0};
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = want_times ? now() : 0.0;
@@ -1463,7 +1523,7 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   struct Restore { vba_ctx *c; bool was; ~Restore() { c->collective_off = was; } } restore{c, c->collective_off};
   if (replicas) c->collective_off = true;                                       // the windows' own LM loops must not enter a collective
   int wi = -1;
-  static const bool want_times = getenv("VBA_HBA_TIMES") != nullptr;
+  static const bool want_times = diag_env("VBA_HBA_TIMES") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_g0 = want_times ? (hipStreamSynchronize(c->stream), now()) : 0.0;
   double t_g1 = 0;
@@ -1585,25 +1645,31 @@ int vba_set_allreduce(vba_ctx *c, vba_allreduce_fn fn, void *user) { c->allreduc
 int vba_rccl_get_unique_id(void *out128) {
   if (!out128) return VBA_ERR_BAD_ARG;
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  const RcclApi &R = rccl_api();
+  if (!R.ok) return VBA_ERR_UNSUPPORTED;
   ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return VBA_ERR_HIP;
+  if (R.GetUniqueId(&id) != ncclSuccess) return VBA_ERR_HIP;
   std::memcpy(out128, &id, sizeof(id));
   return VBA_OK;
 }
 int vba_rccl_init(vba_ctx *c, const void *unique_id128, int rank, int n_ranks) {
   if (!c || !unique_id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return VBA_ERR_BAD_ARG;
-  if (c->comm && c->own_comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  const RcclApi &R = rccl_api();
+  if (!R.ok) { c->set_error(R.why); return VBA_ERR_UNSUPPORTED; }
+  if (c->comm && c->own_comm) { R.CommDestroy(c->comm); c->comm = nullptr; }
   ncclUniqueId id;
   std::memcpy(&id, unique_id128, sizeof(id));
   HIPCHK(c, hipSetDevice(c->device));
-  const ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
-  if (r != ncclSuccess) { c->comm = nullptr; c->set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return VBA_ERR_HIP; }
+  const ncclResult_t r = R.CommInitRank(&c->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; c->set_error(std::string("ncclCommInitRank: ") + R.GetErrorString(r)); return VBA_ERR_HIP; }
   c->own_comm = true;
   return vba_set_shard(c, rank, n_ranks);
 }
 int vba_set_rccl_comm(vba_ctx *c, void *nccl_comm) {
   if (!c) return VBA_ERR_BAD_ARG;
-  if (c->comm && c->own_comm) ncclCommDestroy(c->comm);
+  const RcclApi &R = rccl_api();
+  if (!R.ok) { c->set_error(R.why); return VBA_ERR_UNSUPPORTED; }
+  if (c->comm && c->own_comm) R.CommDestroy(c->comm);
   c->comm = (ncclComm_t)nccl_comm; c->own_comm = false;
   return VBA_OK;
 }
