@@ -20,6 +20,10 @@
 
 namespace vba {
 
+// vba_sort.hip (rocPRIM): stable radix sort of (key, value) pairs on key bits [0, end_bit); tmp == nullptr queries tmp_bytes
+hipError_t sort_pairs_u32(void *tmp, size_t &tmp_bytes, const unsigned int *keys_in, unsigned int *keys_out, const int *vals_in, int *vals_out,
+                          size_t n, unsigned int end_bit, hipStream_t stream);
+
 // 16-bit bucket of a root voxel key; ranks own contiguous bucket ranges
 __host__ __device__ inline uint64_t shard_bucket(int64_t kx, int64_t ky, int64_t kz) {
   uint64_t h = (uint64_t)kx * 0x9E3779B97F4A7C15ull;
@@ -50,6 +54,7 @@ __host__ __device__ inline long long key_axis(double pw, double voxel_size) {
 // free-node stacks that map pruning fills and node creation drains
 enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_SNAP,
        CNT_USED, CNT_FREE_ROOTS, CNT_FREE_BLOCKS,
+       CNT_WL, CNT_SPLIT,          // ordered accumulation: leaf segments of the scan being inserted / leaves split by the current recut level
        CNT_SLIDE_G, CNT_TOUCH_G,   // the two counts the reference's 'fewer voxels than threads' quirks test, summed over the ranks when the map is sharded
        CNT_N };
 
@@ -68,6 +73,8 @@ struct MapView {
   int cap;
   unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nfl2 /* the same before the occupancy sort */; unsigned int *nfkey; int *fhist /* [EXTRACT_NB_MAX] */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
   int *nfree_root, *nfree_blk;   // stacks of recycled node ids: single root nodes / bases of 8-node child blocks (map_prune)
+  int *nseg_a, *nseg_b;          // [W][cap]: the points a scan slot gave to a leaf AT INSERTION = perm[slot][nseg_a .. nseg_b) (scan order)
+  int *nsl;                      // [cap] leaves split by the current recut level
   signed char *nlayer; signed char *nstate;
   unsigned char *f_exist, *f_sw, *f_plane, *f_touched; int *f_slide;
   float *nql; double *ncenter; double *njour;
@@ -79,6 +86,10 @@ struct MapView {
   int *pnode;   // [W][max_pts]
   int *phash;   // [max_pts] temp
   int *newslots;  // [max_pts] temp
+  int *perm;    // [W][max_pts] point indices of a slot grouped by insertion leaf, scan order inside a group (stable sort)
+  unsigned int *skey_a, *skey_b;   // [max_pts] sort keys (leaf id) in / out
+  int *sval_a;  // [max_pts] sort values in (the point index)
+  int *wl;      // [max_pts] leaves that received points of the scan being inserted
   // fixed-point pool
   int cap_fix;
   double *fx;   // [3][cap_fix]
@@ -118,15 +129,68 @@ __device__ __forceinline__ void atomic_bfvar_add(double *base, size_t fstride, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ order-preserving accumulation
+// The reference pushes a leaf's points one by one in SCAN ORDER (cut_voxel VM:1899-1948 / cut_voxel_multi VM:2061-2095 ->
+// allocate -> push VM:1134-1140): pcrs_local, pcr_add and cov_add are chains  ((s + t_1) + t_2) + ...  of separately rounded
+// IEEE operations (the reference targets baseline x86-64: no FMA contraction).  Floating-point addition is not associative, so
+// the only way to reproduce those sums bit for bit is to run the same chains: the scan's points are grouped by leaf with a STABLE
+// sort (scan order survives inside a group), one wave owns a leaf, lane j prepares the terms of the group's j-th point, lane k
+// then adds term k of the points IN ORDER to scalar k of the leaf.  No f64 atomics: the sums do not depend on the run either.
+// Every expression below is written in the reference's operation order with contraction off.
+__device__ __forceinline__ void world_point(const double *R, double bx, double by, double bz, double &x, double &y, double &z) {
+#pragma clang fp contract(off)
+  x = ((R[0] * bx + R[1] * by) + R[2] * bz) + R[9];      // s = 0; s += R(r,k) p(k); ... + t(r)
+  y = ((R[3] * bx + R[4] * by) + R[5] * bz) + R[10];
+  z = ((R[6] * bx + R[7] * by) + R[8] * bz) + R[11];
+}
+
+// terms of one point: [0..8] body cluster (P upper triangle, v), [9..17] world cluster, [18..62] Bf_var upper triangle (VM:106-121);
+// the two point counts are integers and are added outside the chains
+template <bool HAS_VAR>
+struct OrdCfg { static constexpr int NT = HAS_VAR ? 63 : 18; static constexpr int TS = HAS_VAR ? 63 : 19; };   // TS odd: conflict-free rows
+
+template <bool HAS_VAR>
+__device__ __forceinline__ void ord_terms(double *t, double bx, double by, double bz, double x, double y, double z, const double *var) {
+#pragma clang fp contract(off)
+  t[0] = bx * bx; t[1] = bx * by; t[2] = bx * bz; t[3] = by * by; t[4] = by * bz; t[5] = bz * bz; t[6] = bx; t[7] = by; t[8] = bz;
+  t[9] = x * x; t[10] = x * y; t[11] = x * z; t[12] = y * y; t[13] = y * z; t[14] = z * z; t[15] = x; t[16] = y; t[17] = z;
+  if (HAS_VAR) {
+    const double Bi[6][3] = {{2 * x, 0, 0}, {y, x, 0}, {z, 0, x}, {0, 2 * y, 0}, {0, z, y}, {0, 0, 2 * z}};
+    double Bu[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Bu[r][c] = (Bi[r][0] * var[0 * 3 + c] + Bi[r][1] * var[1 * 3 + c]) + Bi[r][2] * var[2 * 3 + c];
+    int idx = 18;
+#pragma unroll
+    for (int r = 0; r < 9; r++)
+#pragma unroll
+      for (int c = r; c < 9; c++) {
+        double val;
+        if (r < 6 && c < 6) val = (Bu[r][0] * Bi[c][0] + Bu[r][1] * Bi[c][1]) + Bu[r][2] * Bi[c][2];
+        else if (r < 6) val = Bu[r][c - 6];
+        else val = var[(r - 6) * 3 + (c - 6)];
+        t[idx++] = val;
+      }
+  }
+}
+// where scalar k of a leaf lives: [0..8] nlc (slot cluster), [9..17] nadd (pcr_add), [18..62] ncov (cov_add)
+__device__ __forceinline__ double *ord_target(const MapView &m, int W, int slot, int k) {
+  const size_t cp = (size_t)m.cap;
+  return k < 9 ? m.nlc + ((size_t)k * W + slot) * cp : k < 18 ? m.nadd + (size_t)(k - 9) * cp : m.ncov + (size_t)(k - 18) * cp;
+}
+
 __device__ __forceinline__ int octant_of(const MapView &m, int node, double x, double y, double z) {
   const size_t cp = (size_t)m.cap;
   const int ox = x > m.ncenter[node] ? 1 : 0, oy = y > m.ncenter[cp + node] ? 1 : 0, oz = z > m.ncenter[2 * cp + node] ? 1 : 0;
   return 4 * ox + 2 * oy + oz;   // VM:1214-1219
 }
 
-__device__ __forceinline__ void init_node(const MapView &m, int id, unsigned long long key, int root, int parent, int layer, int path,
+__device__ __forceinline__ void init_node(const MapView &m, int W, int id, unsigned long long key, int root, int parent, int layer, int path,
                                           double cx, double cy, double cz, float ql) {
   const size_t cp = (size_t)m.cap;
+  for (int sl = 0; sl < W; sl++) { m.nseg_a[(size_t)sl * cp + id] = 0; m.nseg_b[(size_t)sl * cp + id] = 0; }   // (a recycled id must not inherit segments)
   m.nkey[id] = key; m.nroot[id] = root; m.nparent[id] = parent; m.nchild[id] = -1; m.npath[id] = path; m.nopt[id] = -1; m.nlast[id] = 0;
   m.nstamp[id] = 0; m.nsplit[id] = 0; m.ntake[id] = 0; m.nclear[id] = 0; m.ndead[id] = 0;
   m.nlayer[id] = (signed char)layer; m.nstate[id] = 0;
@@ -165,8 +229,7 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
       x = m.fx[(size_t)0 * m.cap_fix + slot + p]; y = m.fx[(size_t)1 * m.cap_fix + slot + p]; z = m.fx[(size_t)2 * m.cap_fix + slot + p];
     } else {
       const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-      const double *R = m.poses;  // the scan pose is staged at poses[0..12)
-      x = R[0] * bx + R[1] * by + R[2] * bz + R[9]; y = R[3] * bx + R[4] * by + R[5] * bz + R[10]; z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
+      world_point(m.poses, bx, by, bz, x, y, z);   // the scan pose is staged at poses[0..12)
     }
     const long long kx = key_axis(x, P.voxel_size), ky = key_axis(y, P.voxel_size), kz = key_axis(z, P.voxel_size);
     bool ok = true;
@@ -247,7 +310,7 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, 
   long long kx, ky, kz;
   const unsigned long long key = m.hkeys[h];
   unpack_key(key, kx, ky, kz);
-  init_node(m, id, key, id, -1, 0, 0, (0.5 + kx) * P.voxel_size, (0.5 + ky) * P.voxel_size, (0.5 + kz) * P.voxel_size, (float)(P.voxel_size / 4.0));
+  init_node(m, P.W, id, key, id, -1, 0, 0, (0.5 + kx) * P.voxel_size, (0.5 + ky) * P.voxel_size, (0.5 + kz) * P.voxel_size, (float)(P.voxel_size / 4.0));
   if (is_fix) m.njour[id] = jour;   // VM:2147
   else {                            // VM:2016-2017: a root created by a window scan enters the sliding map
     m.f_exist[id] = 1; m.f_slide[id] = 1; m.nstamp[id] = stamp;
@@ -257,62 +320,96 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, 
   atomicAdd(&m.cnt[CNT_ROOTS], 1);
 }
 
-// Phase 3: descend to the leaf and accumulate (OctoTree::allocate VM:1204 -> push VM:1105-1143).
-// Neighbouring points of a scan fall into the same few leaves, so the 20 cluster scalars (body-frame slot cluster +
-// world-frame pcr_add) are first summed per leaf in an LDS hash table of the workgroup (ds_add_f64) and only the table's
-// occupied entries go to HBM as f64 atomics: ~N_leaves x 20 instead of 256 x 20 global atomics per workgroup.
-__global__ __launch_bounds__(256) void k_ins_accum(MapView m, MapParams P, int slot, int n, int multi, int has_var) {
-  __shared__ int tkey[256];
-  __shared__ double tacc[20][256];   // 40 KB: three workgroups per CU (512 entries = 82 KB left one, i.e. one wave per SIMD)
-  const int tid = threadIdx.x;
-  tkey[tid] = -1;
-  for (int t = tid; t < 20 * 256; t += 256) (&tacc[0][0])[t] = 0.0;
-  __syncthreads();
-  const int p = blockIdx.x * blockDim.x + tid;
-  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
+// Phase 3: descend to the leaf (OctoTree::allocate VM:1204-1237); the leaf id is the sort key of the point.
+__global__ __launch_bounds__(256) void k_ins_leaf(MapView m, MapParams P, int slot, int n, int multi) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
   const bool dropped = multi && touch_count(m, P) < P.thread_num;   // VM:2044-2045: the scan is dropped
-  if (p < n) {
-    int *pn = m.pnode + (size_t)slot * mpz + p;
-    *pn = -1;
-    const int h = m.phash[p];
-    int node = (!dropped && h >= 0) ? m.hvals[h] : -1;
-    if (node >= 0) {
-      const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-      const double *R = m.poses;
-      const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
-      while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
-      unsigned int e = ((unsigned int)node * 2654435761u) >> 24;
-      while (true) {
-        const int old = atomicCAS(&tkey[e], -1, node);
-        if (old == -1 || old == node) break;
-        e = (e + 1) & 255;
-      }
-      // sw->pcrs_local[mord].push(pv.pnt) VM:1134 ; pcr_add.push(pw) VM:1136
-      unsafeAtomicAdd(&tacc[0][e], bx * bx); unsafeAtomicAdd(&tacc[1][e], bx * by); unsafeAtomicAdd(&tacc[2][e], bx * bz);
-      unsafeAtomicAdd(&tacc[3][e], by * by); unsafeAtomicAdd(&tacc[4][e], by * bz); unsafeAtomicAdd(&tacc[5][e], bz * bz);
-      unsafeAtomicAdd(&tacc[6][e], bx); unsafeAtomicAdd(&tacc[7][e], by); unsafeAtomicAdd(&tacc[8][e], bz); unsafeAtomicAdd(&tacc[9][e], 1.0);
-      unsafeAtomicAdd(&tacc[10][e], x * x); unsafeAtomicAdd(&tacc[11][e], x * y); unsafeAtomicAdd(&tacc[12][e], x * z);
-      unsafeAtomicAdd(&tacc[13][e], y * y); unsafeAtomicAdd(&tacc[14][e], y * z); unsafeAtomicAdd(&tacc[15][e], z * z);
-      unsafeAtomicAdd(&tacc[16][e], x); unsafeAtomicAdd(&tacc[17][e], y); unsafeAtomicAdd(&tacc[18][e], z); unsafeAtomicAdd(&tacc[19][e], 1.0);
-      if (has_var) {
-        double var[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
-        atomic_bfvar_add(m.ncov + node, cp, var, x, y, z);                      // cov_add += Bf_var(pv, pw)      VM:1138-1140
-      }
-      m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1;
-      *pn = node;
+  const int h = m.phash[p];
+  int node = (!dropped && h >= 0) ? m.hvals[h] : -1;
+  if (node >= 0) {
+    const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+    double x, y, z;
+    world_point(m.poses, bx, by, bz, x, y, z);
+    while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+    m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1;
+  }
+  m.pnode[(size_t)slot * mpz + p] = node;
+  m.skey_a[p] = node >= 0 ? (unsigned int)node : 0xFFFFFFFFu;
+  m.sval_a[p] = p;
+}
+
+// Phase 4 (after the stable sort by leaf): group boundaries -> the leaf's segment [nseg_a, nseg_b) of perm[slot]; the leaf joins the work list.
+__global__ __launch_bounds__(256) void k_ins_heads(MapView m, int slot, int n) {
+  __shared__ int wbase[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t cp = (size_t)m.cap;
+  unsigned int key = 0xFFFFFFFFu;
+  bool head = false;
+  if (i < n) {
+    key = m.skey_b[i];
+    if (key != 0xFFFFFFFFu) {
+      head = (i == 0) || m.skey_b[i - 1] != key;
+      const bool tail = (i == n - 1) || m.skey_b[i + 1] != key;
+      if (head) m.nseg_a[(size_t)slot * cp + key] = i;
+      if (tail) m.nseg_b[(size_t)slot * cp + key] = i + 1;
     }
   }
+  const unsigned long long mask = __ballot(head);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = __popcll(mask);
   __syncthreads();
-  for (int t = tid; t < 20 * 256; t += 256) {
-    const int k = t >> 8, e = t & 255;
-    const int node = tkey[e];
-    if (node < 0) continue;
-    const double v = tacc[k][e];
-    if (v == 0.0) continue;
-    if (k < 10) unsafeAtomicAdd(m.nlc + ((size_t)k * W + slot) * cp + node, v);
-    else unsafeAtomicAdd(m.nadd + (size_t)(k - 10) * cp + node, v);
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int base = tot ? atomicAdd(&m.cnt[CNT_WL], tot) : 0;
+    for (int w = 0; w < 4; w++) wbase[w] += base;
+  }
+  __syncthreads();
+  if (head) m.wl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)key;   // (the order of the list carries no meaning)
+}
+
+// Phase 5: one wave per leaf of the work list — push VM:1129-1140 for the leaf's points in scan order.
+template <bool HAS_VAR>
+__global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, int slot) {
+  using C = OrdCfg<HAS_VAR>;
+  __shared__ double T[64 * C::TS];
+  const int lane = threadIdx.x;
+  const int nseg = m.cnt[CNT_WL];
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
+  const int *perm = m.perm + (size_t)slot * mpz;
+  double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0);
+  for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const int leaf = m.wl[s];
+    const int start = m.nseg_a[(size_t)slot * cp + leaf], end = m.nseg_b[(size_t)slot * cp + leaf];
+    double acc = lane < C::NT ? tgt[leaf] : 0.0;
+    for (int c0 = start; c0 < end; c0 += 64) {
+      const int i = c0 + lane;
+      if (i < end) {
+        const int p = perm[i];
+        const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+        double var[9];
+        if (HAS_VAR) {
+#pragma unroll
+          for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+        }
+        double x, y, z;
+        world_point(m.poses, bx, by, bz, x, y, z);
+        ord_terms<HAS_VAR>(T + lane * C::TS, bx, by, bz, x, y, z, var);
+      }
+      __syncthreads();
+      const int cnt = end - c0 < 64 ? end - c0 : 64;
+      if (lane < C::NT)
+        for (int j = 0; j < cnt; j++) acc += T[j * C::TS + lane];
+      __syncthreads();
+    }
+    if (lane < C::NT) tgt[leaf] = acc;
+    if (lane == 63) {                                   // N of both clusters: integers, exact in f64
+      const double dn = (double)(end - start);
+      m.nlc[((size_t)9 * W + slot) * cp + leaf] += dn;
+      m.nadd[(size_t)9 * cp + leaf] += dn;
+    }
   }
 }
 
@@ -346,70 +443,152 @@ __device__ __forceinline__ bool in_scope(const MapView &m, const MapParams &P, i
 // The grid covers the node CAPACITY; the live range is the node count snapshotted on the device before the launch
 // (CNT_SNAP) — nodes created by this launch's own splits must not be visited by it, and reading the count back to size
 // the grid cost one ~18 us host round trip per level.
-__global__ void k_recut_leaf(MapView m, MapParams P, int L, int multi, int epoch) {
+__global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int L, int multi, int epoch) {
+  __shared__ int wbase[4];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_SNAP] < m.cap ? m.cnt[CNT_SNAP] : m.cap;
-  if (id >= nn) return;
-  if (m.nlayer[id] != L || m.nstate[id] != 0) return;
-  if (multi && slide_count(m, P) < P.thread_num) return;   // VS:1693-1694
-  if (!in_scope(m, P, id, multi)) return;
   const size_t cp = (size_t)m.cap;
-  m.nopt[id] = -1;
-  const double N = m.nadd[9 * cp + id];
-  if (N <= P.min_point[L]) { m.f_plane[id] = 0; return; }   // VM:1406-1410
-  if (!m.f_exist[id] || !m.f_sw[id]) return;                // VM:1412-1413
-  const double b0 = m.nadd[6 * cp + id] / N, b1 = m.nadd[7 * cp + id] / N, b2 = m.nadd[8 * cp + id] / N;
-  double w0, w1, w2, V[9];
-  eig3_sym_dev(m.nadd[0 * cp + id] / N - b0 * b0, m.nadd[1 * cp + id] / N - b1 * b0, m.nadd[2 * cp + id] / N - b2 * b0,
-               m.nadd[3 * cp + id] / N - b1 * b1, m.nadd[4 * cp + id] / N - b2 * b1, m.nadd[5 * cp + id] / N - b2 * b2, w0, w1, w2, V);
-  m.neval[id] = w0; m.neval[cp + id] = w1; m.neval[2 * cp + id] = w2;
+  bool split = false;
+  do {
+    if (id >= nn) break;
+    if (m.nlayer[id] != L || m.nstate[id] != 0) break;
+    if (multi && slide_count(m, P) < P.thread_num) break;   // VS:1693-1694
+    if (!in_scope(m, P, id, multi)) break;
+    m.nopt[id] = -1;
+    const double N = m.nadd[9 * cp + id];
+    if (N <= P.min_point[L]) { m.f_plane[id] = 0; break; }   // VM:1406-1410
+    if (!m.f_exist[id] || !m.f_sw[id]) break;                // VM:1412-1413
+    const double b0 = m.nadd[6 * cp + id] / N, b1 = m.nadd[7 * cp + id] / N, b2 = m.nadd[8 * cp + id] / N;
+    double w0, w1, w2, V[9];
+    eig3_sym_dev(m.nadd[0 * cp + id] / N - b0 * b0, m.nadd[1 * cp + id] / N - b1 * b0, m.nadd[2 * cp + id] / N - b2 * b0,
+                 m.nadd[3 * cp + id] / N - b1 * b1, m.nadd[4 * cp + id] / N - b2 * b1, m.nadd[5 * cp + id] / N - b2 * b2, w0, w1, w2, V);
+    m.neval[id] = w0; m.neval[cp + id] = w1; m.neval[2 * cp + id] = w2;
 #pragma unroll
-  for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = V[k];
-  const bool plane = (w0 < P.min_eigen_value) && ((w0 / w2) < P.plane_thre[L]);   // plane_judge VM:1194
-  m.f_plane[id] = plane ? 1 : 0;
-  if (plane || L >= P.max_layer) return;
-  // subdivide: children are created as a block of 8 (untouched octants stay empty leaves, which every traversal skips)
-  const int base = alloc_nodes(m, CNT_FREE_BLOCKS, m.nfree_blk, 8);
-  if (base + 8 > m.cap) { m.cnt[CNT_OVERFLOW] = 1; return; }
-  const double cx = m.ncenter[id], cy = m.ncenter[cp + id], cz = m.ncenter[2 * cp + id];
-  const float ql = m.nql[id];
-  for (int o = 0; o < 8; o++) {
-    const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
-    // VM:1227-1231: double + int * float
-    init_node(m, base + o, m.nkey[id], m.nroot[id], id, L + 1, (L == 0 ? o : m.npath[id] * 8 + o), cx + (2 * ox - 1) * ql, cy + (2 * oy - 1) * ql,
-              cz + (2 * oz - 1) * ql, ql / 2);
+    for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = V[k];
+    const bool plane = (w0 < P.min_eigen_value) && ((w0 / w2) < P.plane_thre[L]);   // plane_judge VM:1194
+    m.f_plane[id] = plane ? 1 : 0;
+    if (plane || L >= P.max_layer) break;
+    // subdivide: children are created as a block of 8 (untouched octants stay empty leaves, which every traversal skips)
+    const int base = alloc_nodes(m, CNT_FREE_BLOCKS, m.nfree_blk, 8);
+    if (base + 8 > m.cap) { m.cnt[CNT_OVERFLOW] = 1; break; }
+    const double cx = m.ncenter[id], cy = m.ncenter[cp + id], cz = m.ncenter[2 * cp + id];
+    const float ql = m.nql[id];
+    for (int o = 0; o < 8; o++) {
+      const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
+      // VM:1227-1231: double + int * float
+      init_node(m, P.W, base + o, m.nkey[id], m.nroot[id], id, L + 1, (L == 0 ? o : m.npath[id] * 8 + o), cx + (2 * ox - 1) * ql, cy + (2 * oy - 1) * ql,
+                cz + (2 * oz - 1) * ql, ql / 2);
+    }
+    m.nchild[id] = base;
+    m.nsplit[id] = epoch;    // the point kernels of this pass move this leaf's points to the children
+    m.nstate[id] = 1;        // VM:1449
+    m.f_sw[id] = 0;          // sw->clear(); sws.push_back(sw); sw = nullptr  VM:1445-1447
+    for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
+    split = true;
+  } while (false);
+  // the leaves this level split form the work list of k_recut_push (one returning atomic per workgroup; the order carries no meaning)
+  const unsigned long long mask = __ballot(split);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int base = tot ? atomicAdd(&m.cnt[CNT_SPLIT], tot) : 0;
+    for (int w = 0; w < 4; w++) wbase[w] += base;
   }
-  m.nchild[id] = base;
-  m.nsplit[id] = epoch;    // the point kernels of this pass move this leaf's points to the children
-  m.nstate[id] = 1;        // VM:1449
-  m.f_sw[id] = 0;          // sw->clear(); sws.push_back(sw); sw = nullptr  VM:1445-1447
-  for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
+  __syncthreads();
+  if (split) m.nsl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = id;
 }
 
-// Window points of split leaves -> children, keyed with the CURRENT poses (subdivide VM:1307-1338 + push).
-__global__ void k_recut_points(MapView m, MapParams P, int win_count, int epoch, int has_var) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int fi = blockIdx.y;   // frame
-  if (p >= m.max_pts || fi >= win_count) return;
+// Window points of split leaves -> children, keyed with the CURRENT poses (subdivide VM:1307-1338 + push VM:1105-1143), in the
+// reference's order: frames 0 .. win_count-1, inside a frame the leaf's points in scan order.  One wave per split leaf X.  X's points
+// of a slot are the entries with pnode == X inside the segment the slot gave to X — or to the ancestor of X that was the leaf when the
+// scan was inserted — in perm order (= scan order).  Per chunk of 64 candidates lane j prepares point j's terms; the eight children
+// are then served one after the other: lane k adds term k of the child's points, in order, to the child's scalar k (kept in LDS
+// between chunks).  The children were created empty by this level's k_recut_leaf, so every chain starts from zero like a new OctoTree.
+template <bool HAS_VAR>
+__global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int win_count) {
+  using C = OrdCfg<HAS_VAR>;
+  __shared__ double T[64 * C::TS];
+  __shared__ double A[8 * 64];          // child accumulators: [0..8] body cluster of the current frame, [9..17] pcr_add, [18..62] cov_add
+  __shared__ int cj[64];
+  __shared__ int nw[8], nb[8];          // points per child: whole window / current frame
+  const int lane = threadIdx.x;
+  const int nsplit = m.cnt[CNT_SPLIT];
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
-  const int slot = P.mp[fi];
-  int *pn = m.pnode + (size_t)slot * mpz + p;
-  const int node = *pn;
-  if (node < 0 || m.nsplit[node] != epoch) return;
-  const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-  const double *R = m.poses + 12 * fi;
-  const double x = R[0] * bx + R[1] * by + R[2] * bz + R[9], y = R[3] * bx + R[4] * by + R[5] * bz + R[10], z = R[6] * bx + R[7] * by + R[8] * bz + R[11];
-  const int child = m.nchild[node] + octant_of(m, node, x, y, z);
-  atomic_cluster_add(m.nlc + (size_t)slot * cp + child, W * cp, bx, by, bz);
-  atomic_cluster_add(m.nadd + child, cp, x, y, z);
-  if (has_var) {
-    double var[9];
+  for (int s = blockIdx.x; s < nsplit; s += gridDim.x) {
+    const int X = m.nsl[s];
+    const int base = m.nchild[X];
 #pragma unroll
-    for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
-    atomic_bfvar_add(m.ncov + child, cp, var, x, y, z);
+    for (int c = 0; c < 8; c++) A[c * 64 + lane] = 0.0;
+    if (lane < 8) nw[lane] = 0;
+    for (int fi = 0; fi < win_count; fi++) {
+      const int slot = P.mp[fi];
+      int anc = X;                       // the node that was the leaf when this slot's scan was inserted
+      while (anc >= 0 && m.nseg_b[(size_t)slot * cp + anc] == m.nseg_a[(size_t)slot * cp + anc]) anc = m.nparent[anc];
+      if (anc < 0) continue;             // the frame gave X nothing
+      const int start = m.nseg_a[(size_t)slot * cp + anc], end = m.nseg_b[(size_t)slot * cp + anc];
+      const int *perm = m.perm + (size_t)slot * mpz;
+      int *pnode = m.pnode + (size_t)slot * mpz;
+      if (lane < 8) nb[lane] = 0;
+      if (lane < 9) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) A[c * 64 + lane] = 0.0;
+      }
+      __syncthreads();
+      for (int c0 = start; c0 < end; c0 += 64) {
+        const int i = c0 + lane;
+        int child = -1;
+        if (i < end) {
+          const int p = perm[i];
+          if (pnode[p] == X) {
+            const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+            double var[9];
+            if (HAS_VAR) {
+#pragma unroll
+              for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+            }
+            double x, y, z;
+            world_point(m.poses + 12 * fi, bx, by, bz, x, y, z);
+            child = octant_of(m, X, x, y, z);
+            ord_terms<HAS_VAR>(T + lane * C::TS, bx, by, bz, x, y, z, var);
+            pnode[p] = base + child;
+          }
+        }
+        cj[lane] = child;
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < 8; c++) {
+          unsigned long long mk = __ballot(child == c);
+          if (mk == 0ull) continue;
+          if (lane == 63) { const int n = __popcll(mk); nw[c] += n; nb[c] += n; }
+          if (lane < C::NT) {
+            double acc = A[c * 64 + lane];
+            while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * C::TS + lane]; }
+            A[c * 64 + lane] = acc;
+          }
+        }
+        __syncthreads();
+      }
+      // the frame's body clusters of the children (pcrs_local[mp[fi]] of each new leaf)
+#pragma unroll 1
+      for (int c = 0; c < 8; c++) {
+        if (nb[c] == 0) continue;
+        if (lane < 9) m.nlc[((size_t)lane * W + slot) * cp + base + c] = A[c * 64 + lane];
+        if (lane == 9) m.nlc[((size_t)9 * W + slot) * cp + base + c] = (double)nb[c];
+      }
+      __syncthreads();
+    }
+#pragma unroll 1
+    for (int c = 0; c < 8; c++) {
+      if (nw[c] == 0) continue;
+      const int ch = base + c;
+      if (lane >= 9 && lane < C::NT) ord_target(m, P.W, 0, lane)[ch] = A[c * 64 + lane];
+      if (lane == 63) { m.nadd[(size_t)9 * cp + ch] = (double)nw[c]; m.f_sw[ch] = 1; m.f_exist[ch] = 1; m.f_touched[ch] = 1; }
+    }
+    __syncthreads();
   }
-  m.f_sw[child] = 1; m.f_exist[child] = 1; m.f_touched[child] = 1;
-  *pn = child;
 }
 
 // Fixed points of split leaves -> children (fix_divide VM:1270-1299 + push_fix VM:1149-1162).
@@ -902,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_odom_match(MapView m, MapParams P, Odom
 #pragma unroll
           for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) RV[3 * r + c] = R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c] + R[3 * r + 2] * v[6 + c];
+            for (int c = 0; c < 3; c++) RV[3 * r + c] = (R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c]) + R[3 * r + 2] * v[6 + c];
           const double ph[9] = {0, -bz, by, bz, 0, -bx, -by, bx, 0};
           double PR[9];
 #pragma unroll
@@ -1063,6 +1242,7 @@ __global__ void k_var_init(int n, const double *__restrict__ pin, double *__rest
 // pvec_update (voxelslam.hpp:242-265) fused into the staging of a scan: var_world = R var R^T + phat rot_var phat^T + tsl_var
 // (pw = R p + t is recomputed by the insert kernels).  cov6 = [rot_var(9) | tsl_var(9)].
 __global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, const double *pts, const double *var, const double *pose, const double *cov6) {
+#pragma clang fp contract(off)      // the reference's operation order, separately rounded (cov_add sums these values in order: see ord_terms)
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts;
@@ -1075,18 +1255,18 @@ __global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, con
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) RV[3 * r + c] = R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c] + R[3 * r + 2] * v[6 + c];
+    for (int c = 0; c < 3; c++) RV[3 * r + c] = (R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c]) + R[3 * r + 2] * v[6 + c];
   const double ph[9] = {0, -bz, by, bz, 0, -bx, -by, bx, 0};
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) PR[3 * r + c] = ph[3 * r] * cov6[c] + ph[3 * r + 1] * cov6[3 + c] + ph[3 * r + 2] * cov6[6 + c];
+    for (int c = 0; c < 3; c++) PR[3 * r + c] = (ph[3 * r] * cov6[c] + ph[3 * r + 1] * cov6[3 + c]) + ph[3 * r + 2] * cov6[6 + c];
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
     for (int c = 0; c < 3; c++)
-      m.pvar[((size_t)(3 * r + c) * W + slot) * mpz + p] = (RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1] + RV[3 * r + 2] * R[3 * c + 2]) +
-                                                           (PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1] + PR[3 * r + 2] * ph[3 * c + 2]) + cov6[9 + 3 * r + c];
+      m.pvar[((size_t)(3 * r + c) * W + slot) * mpz + p] = (((RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1]) + RV[3 * r + 2] * R[3 * c + 2]) +
+                                                            ((PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1]) + PR[3 * r + 2] * ph[3 * c + 2])) + cov6[9 + 3 * r + c];
 }
 
 // AoS host layout [n][3] / [n][9] -> the scan slot's SoA arrays
@@ -1129,6 +1309,7 @@ struct MapStore {
   bool cnt_stale = false;
   double *h_pose_ring = nullptr; hipEvent_t pose_ev[8] = {nullptr}; int pose_next = 0;
   void *d_stage = nullptr; size_t stage_bytes = 0;
+  void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; int sort_tmp_for = 0;   // rocPRIM scratch, sized for max_pts pairs
   // sharded map: SUM all-reduce of n doubles in HBM over the ranks, stream-ordered (set by the context); d_gc = its 2-double scratch
   std::function<int(double *, size_t)> allreduce;
   double *d_gc = nullptr;
@@ -1159,14 +1340,16 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
   return {
       {(void **)&v.nkey, 8, 1}, {(void **)&v.nroot, 4, 1}, {(void **)&v.nparent, 4, 1}, {(void **)&v.nchild, 4, 1}, {(void **)&v.npath, 4, 1},
       {(void **)&v.nopt, 4, 1}, {(void **)&v.nflist, 4, 1}, {(void **)&v.nfl2, 4, 1}, {(void **)&v.nfkey, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
-      {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nfree_root, 4, 1}, {(void **)&v.nfree_blk, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
+      {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nfree_root, 4, 1}, {(void **)&v.nfree_blk, 4, 1},
+      {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
       {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
       {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, 8, (size_t)10 * W},
   };
 }
 inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
-  return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1}};
+  return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1},
+          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.wl, 4, 1}};
 }
 inline std::vector<DevArr> fix_arrays(MapView &v) { return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}}; }
 
@@ -1286,6 +1469,7 @@ inline void map_free(MapStore &s) {
   if (s.h_pose_ring) hipHostFree(s.h_pose_ring);
   for (int i = 0; i < 8; i++) if (s.pose_ev[i]) hipEventDestroy(s.pose_ev[i]);
   if (s.d_stage) hipFree(s.d_stage);
+  if (s.d_sort_tmp) { hipFree(s.d_sort_tmp); s.d_sort_tmp = nullptr; s.sort_tmp_bytes = 0; s.sort_tmp_for = 0; }
   if (s.d_gc) { hipFree(s.d_gc); s.d_gc = nullptr; }
   s.v = MapView{};
   s.allocated = false;
@@ -1373,7 +1557,35 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, 0, s.stamp);
   hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0, s.stamp);
   if (multi) { r = map_global_count(s, st, CNT_TOUCH, CNT_TOUCH_G, err); if (r) return r; }   // VM:2044 tests the whole scan's voxel count
-  hipLaunchKernelGGL(k_ins_accum, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0, var ? 1 : 0);
+  // order-preserving accumulation: leaf of every point -> stable sort by leaf -> segments -> one wave per leaf adds in scan order
+  if (s.sort_tmp_for < s.v.max_pts) {
+    size_t need = 0;
+    MAPCHK(sort_pairs_u32(nullptr, need, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.perm, (size_t)s.v.max_pts, 32u, st));
+    if (need > s.sort_tmp_bytes) {
+      MAPCHK(hipStreamSynchronize(st));
+      if (s.d_sort_tmp) hipFree(s.d_sort_tmp);
+      s.d_sort_tmp = nullptr; s.sort_tmp_bytes = 0;
+      MAPCHK(hipMalloc(&s.d_sort_tmp, need + 256));
+      s.sort_tmp_bytes = need + 256;
+    }
+    s.sort_tmp_for = s.v.max_pts;
+  }
+  MAPCHK(hipMemsetAsync(s.v.nseg_a + (size_t)slot * s.v.cap, 0, (size_t)s.v.cap * 4, st));   // the slot's previous occupant is gone
+  MAPCHK(hipMemsetAsync(s.v.nseg_b + (size_t)slot * s.v.cap, 0, (size_t)s.v.cap * 4, st));
+  r = map_set_counter(s, st, CNT_WL, 0, err); if (r) return r;
+  hipLaunchKernelGGL(k_ins_leaf, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0);
+  {
+    unsigned int bits = 1;                       // node ids < cap; "no leaf" = all ones, which must sort behind every id
+    while (bits < 32 && (1ull << bits) <= (unsigned long long)s.v.cap) bits++;
+    size_t tb = s.sort_tmp_bytes;
+    MAPCHK(sort_pairs_u32(s.d_sort_tmp, tb, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.perm + (size_t)slot * s.v.max_pts, (size_t)n, bits, st));
+  }
+  hipLaunchKernelGGL(k_ins_heads, dim3(nb), dim3(256), 0, st, s.v, slot, n);
+  {
+    const int nwg = n < 8192 ? n : 8192;         // one wave per leaf of the work list, grid-stride (the list length stays on the device)
+    if (var) hipLaunchKernelGGL((k_ins_accum_ord<true>), dim3(nwg), dim3(64), 0, st, s.v, P, slot);
+    else hipLaunchKernelGGL((k_ins_accum_ord<false>), dim3(nwg), dim3(64), 0, st, s.v, P, slot);
+  }
   MAPCHK(hipGetLastError());
   // no read-back: capacity was reserved for the worst case (n new roots), so this call cannot overflow
   s.ub_nodes += n; s.ub_roots += n; s.ub_used += n; s.cnt_stale = true;
@@ -1436,10 +1648,13 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
       for (int L = 0; L <= s.opt.max_layer; L++) {
         s.epoch++;
         hipLaunchKernelGGL(k_copy_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_NODES, (int)CNT_SNAP);
+        hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_SPLIT, 0);
         hipLaunchKernelGGL(k_recut_leaf, dim3(grid_nodes), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
         if (L < s.opt.max_layer) {
-          if (max_n > 0 && win_count > 0)
-            hipLaunchKernelGGL(k_recut_points, dim3((max_n + 255) / 256, win_count), dim3(256), 0, st, s.v, P, win_count, s.epoch, s.have_var ? 1 : 0);
+          if (max_n > 0 && win_count > 0) {      // (before the fixed points: it STORES the children's sums, k_recut_fixpts adds to them)
+            if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(64), 0, st, s.v, P, win_count);
+            else hipLaunchKernelGGL((k_recut_push<false>), dim3(4096), dim3(64), 0, st, s.v, P, win_count);
+          }
           if (s.h_cnt[CNT_FIX] > 0)
             hipLaunchKernelGGL(k_recut_fixpts, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v, P, s.epoch, L + 1);
         }
