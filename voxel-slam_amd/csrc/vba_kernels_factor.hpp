@@ -189,6 +189,34 @@ __global__ __launch_bounds__(256) void k_calib_read8(const double *__restrict__ 
 // transform of all W frames for every lane (exec-masked lanes still cost issue cycles): 950 f64 instructions x 4 cycles = 3.8k of
 // the pass's 22k cycles, and the Jacobi eigen-solve another 8.5k (in-kernel stamps, profiles/r01_k3_stamps.txt); one lane per slot
 // issues the transform once per wave, and ~3 waves per SIMD (instead of 0.3) overlap each other's memory trips.
+// PointCluster::transform (tools.hpp:357-363) in the reference's operation order, every operation rounded separately (the
+// reference targets baseline x86-64: no FMA contraction):  v' = R v + p N ;  rp = (R v) p^T ;  P' = ((R P R^T + rp) + rp^T) + (p p^T) N,
+// matrix products as left-to-right dot products.  The six P scalars of a cluster are its LOWER triangle (what the eigen-solver of the
+// reference reads, and what the pushes make symmetric anyway).  With the frames added in frame order (VM:297-305) pcr_adds — which
+// margi copies into the map (VM:1498-1500) — comes out bit-identical to the CPU restatement's, so the map's sums stay exact over a session.
+struct Cl10 { double p00, p10, p20, p11, p21, p22, v0, v1, v2, n; };
+__device__ __forceinline__ Cl10 cluster_transform_exact(double c0, double c1, double c2, double c3, double c4, double c5, double v0, double v1, double v2, double n,
+                                                        const double *R) {
+#pragma clang fp contract(off)
+  const double R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5], R6 = R[6], R7 = R[7], R8 = R[8];
+  const double tx = R[9], ty = R[10], tz = R[11];
+  const double rv0 = (R0 * v0 + R1 * v1) + R2 * v2, rv1 = (R3 * v0 + R4 * v1) + R5 * v2, rv2 = (R6 * v0 + R7 * v1) + R8 * v2;
+  // M = R P (P symmetric: P01 = c1, P02 = c2, P12 = c4)
+  const double m00 = (R0 * c0 + R1 * c1) + R2 * c2, m01 = (R0 * c1 + R1 * c3) + R2 * c4, m02 = (R0 * c2 + R1 * c4) + R2 * c5;
+  const double m10 = (R3 * c0 + R4 * c1) + R5 * c2, m11 = (R3 * c1 + R4 * c3) + R5 * c4, m12 = (R3 * c2 + R4 * c4) + R5 * c5;
+  const double m20 = (R6 * c0 + R7 * c1) + R8 * c2, m21 = (R6 * c1 + R7 * c3) + R8 * c4, m22 = (R6 * c2 + R7 * c4) + R8 * c5;
+  Cl10 o;
+  o.p00 = ((((m00 * R0 + m01 * R1) + m02 * R2) + rv0 * tx) + rv0 * tx) + (tx * tx) * n;
+  o.p10 = ((((m10 * R0 + m11 * R1) + m12 * R2) + rv1 * tx) + rv0 * ty) + (ty * tx) * n;
+  o.p20 = ((((m20 * R0 + m21 * R1) + m22 * R2) + rv2 * tx) + rv0 * tz) + (tz * tx) * n;
+  o.p11 = ((((m10 * R3 + m11 * R4) + m12 * R5) + rv1 * ty) + rv1 * ty) + (ty * ty) * n;
+  o.p21 = ((((m20 * R3 + m21 * R4) + m22 * R5) + rv2 * ty) + rv1 * tz) + (tz * ty) * n;
+  o.p22 = ((((m20 * R6 + m21 * R7) + m22 * R8) + rv2 * tz) + rv2 * tz) + (tz * tz) * n;
+  o.v0 = rv0 + tx * n; o.v1 = rv1 + ty * n; o.v2 = rv2 + tz * n;
+  o.n = n;
+  return o;
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
   return x;
@@ -275,26 +303,9 @@ __global__ __launch_bounds__((ResCfg<W, TV>::NT)) void k_residual_s(FactorView f
   if (occ) n = f.cl[9 * fs + (size_t)fi * vs + v];
   __syncthreads();
   if (occ) {
-    const double pxx = c[0], pxy = c[1], pxz = c[2], pyy = c[3], pyz = c[4], pzz = c[5];
-    const double vx = c[6], vy = c[7], vz = c[8];
-    const double *R = sp + 12 * fi;
-    const double R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5], R6 = R[6], R7 = R[7], R8 = R[8];
-    const double tx = R[9], ty = R[10], tz = R[11];
-    // Rv = R v ; v' = Rv + n t                                  (tools.hpp:360)
-    const double rv0 = R0 * vx + R1 * vy + R2 * vz;
-    const double rv1 = R3 * vx + R4 * vy + R5 * vz;
-    const double rv2 = R6 * vx + R7 * vy + R8 * vz;
-    // M = R P (3x3), then (R P R^T) lower triangle               (tools.hpp:362)
-    const double m00 = R0 * pxx + R1 * pxy + R2 * pxz, m01 = R0 * pxy + R1 * pyy + R2 * pyz, m02 = R0 * pxz + R1 * pyz + R2 * pzz;
-    const double m10 = R3 * pxx + R4 * pxy + R5 * pxz, m11 = R3 * pxy + R4 * pyy + R5 * pyz, m12 = R3 * pxz + R4 * pyz + R5 * pzz;
-    const double m20 = R6 * pxx + R7 * pxy + R8 * pxz, m21 = R6 * pxy + R7 * pyy + R8 * pyz, m22 = R6 * pxz + R7 * pyz + R8 * pzz;
-    T[0][fi][vl] = (m00 * R0 + m01 * R1 + m02 * R2) + 2.0 * rv0 * tx + n * tx * tx;
-    T[1][fi][vl] = (m10 * R0 + m11 * R1 + m12 * R2) + (rv1 * tx + rv0 * ty) + n * ty * tx;
-    T[2][fi][vl] = (m20 * R0 + m21 * R1 + m22 * R2) + (rv2 * tx + rv0 * tz) + n * tz * tx;
-    T[3][fi][vl] = (m10 * R3 + m11 * R4 + m12 * R5) + 2.0 * rv1 * ty + n * ty * ty;
-    T[4][fi][vl] = (m20 * R3 + m21 * R4 + m22 * R5) + (rv2 * ty + rv1 * tz) + n * tz * ty;
-    T[5][fi][vl] = (m20 * R6 + m21 * R7 + m22 * R8) + 2.0 * rv2 * tz + n * tz * tz;
-    T[6][fi][vl] = rv0 + n * tx; T[7][fi][vl] = rv1 + n * ty; T[8][fi][vl] = rv2 + n * tz;
+    const Cl10 w = cluster_transform_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], n, sp + 12 * fi);   // tools.hpp:357-363
+    T[0][fi][vl] = w.p00; T[1][fi][vl] = w.p10; T[2][fi][vl] = w.p20; T[3][fi][vl] = w.p11; T[4][fi][vl] = w.p21; T[5][fi][vl] = w.p22;
+    T[6][fi][vl] = w.v0; T[7][fi][vl] = w.v1; T[8][fi][vl] = w.v2;
     T[9][fi][vl] = n;
   } else if (fi < W) {
 #pragma unroll
@@ -390,26 +401,10 @@ __global__ __launch_bounds__(64) void k_residual_v(FactorView f, const double *_
   for (int i = 0; i < W; i++) {
     const bool on = (occm >> i) & 1u;
     if (__ballot(on) != 0ull) {
-      const double *R = poses + 12 * i;                           // uniform address: scalar loads
-      const double R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5], R6 = R[6], R7 = R[7], R8 = R[8];
-      const double tx = R[9], ty = R[10], tz = R[11];
       if (on) {
-        const double pxx = c[i][0], pxy = c[i][1], pxz = c[i][2], pyy = c[i][3], pyz = c[i][4], pzz = c[i][5];
-        const double vx = c[i][6], vy = c[i][7], vz = c[i][8], n = c[i][9];
-        const double rv0 = R0 * vx + R1 * vy + R2 * vz;
-        const double rv1 = R3 * vx + R4 * vy + R5 * vz;
-        const double rv2 = R6 * vx + R7 * vy + R8 * vz;
-        const double m00 = R0 * pxx + R1 * pxy + R2 * pxz, m01 = R0 * pxy + R1 * pyy + R2 * pyz, m02 = R0 * pxz + R1 * pyz + R2 * pzz;
-        const double m10 = R3 * pxx + R4 * pxy + R5 * pxz, m11 = R3 * pxy + R4 * pyy + R5 * pyz, m12 = R3 * pxz + R4 * pyz + R5 * pzz;
-        const double m20 = R6 * pxx + R7 * pxy + R8 * pxz, m21 = R6 * pxy + R7 * pyy + R8 * pyz, m22 = R6 * pxz + R7 * pyz + R8 * pzz;
-        acc[0] += (m00 * R0 + m01 * R1 + m02 * R2) + 2.0 * rv0 * tx + n * tx * tx;
-        acc[1] += (m10 * R0 + m11 * R1 + m12 * R2) + (rv1 * tx + rv0 * ty) + n * ty * tx;
-        acc[2] += (m20 * R0 + m21 * R1 + m22 * R2) + (rv2 * tx + rv0 * tz) + n * tz * tx;
-        acc[3] += (m10 * R3 + m11 * R4 + m12 * R5) + 2.0 * rv1 * ty + n * ty * ty;
-        acc[4] += (m20 * R3 + m21 * R4 + m22 * R5) + (rv2 * ty + rv1 * tz) + n * tz * ty;
-        acc[5] += (m20 * R6 + m21 * R7 + m22 * R8) + 2.0 * rv2 * tz + n * tz * tz;
-        acc[6] += rv0 + n * tx; acc[7] += rv1 + n * ty; acc[8] += rv2 + n * tz;
-        acc[9] += n;
+        const Cl10 w = cluster_transform_exact(c[i][0], c[i][1], c[i][2], c[i][3], c[i][4], c[i][5], c[i][6], c[i][7], c[i][8], c[i][9], poses + 12 * i);
+        acc[0] += w.p00; acc[1] += w.p10; acc[2] += w.p20; acc[3] += w.p11; acc[4] += w.p21; acc[5] += w.p22;
+        acc[6] += w.v0; acc[7] += w.v1; acc[8] += w.v2; acc[9] += w.n;
       }
     }
   }

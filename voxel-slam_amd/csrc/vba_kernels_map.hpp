@@ -54,6 +54,7 @@ __host__ __device__ inline long long key_axis(double pw, double voxel_size) {
 // free-node stacks that map pruning fills and node creation drains
 enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_SNAP,
        CNT_USED, CNT_FREE_ROOTS, CNT_FREE_BLOCKS,
+       CNT_FBLK, CNT_TAKE,         // blocks of the fixed-point pool / leaves whose oldest frame moves to the pool in this margi
        CNT_WL, CNT_SPLIT,          // ordered accumulation: leaf segments of the scan being inserted / leaves split by the current recut level
        CNT_SLIDE_G, CNT_TOUCH_G,   // the two counts the reference's 'fewer voxels than threads' quirks test, summed over the ranks when the map is sharded
        CNT_N };
@@ -74,7 +75,8 @@ struct MapView {
   unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nfl2 /* the same before the occupancy sort */; unsigned int *nfkey; int *fhist /* [EXTRACT_NB_MAX] */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
   int *nfree_root, *nfree_blk;   // stacks of recycled node ids: single root nodes / bases of 8-node child blocks (map_prune)
   int *nseg_a, *nseg_b;          // [W][cap]: the points a scan slot gave to a leaf AT INSERTION = perm[slot][nseg_a .. nseg_b) (scan order)
-  int *nsl;                      // [cap] leaves split by the current recut level
+  int *nsl;                      // [cap] leaves split by the current recut level (margi: leaves whose oldest frame joins the fixed points)
+  int *nfb_head, *nfb_tail;      // [cap] a leaf's fixed points (point_fix) arrive in BLOCKS of consecutive pool entries; the blocks are chained in arrival order
   signed char *nlayer; signed char *nstate;
   unsigned char *f_exist, *f_sw, *f_plane, *f_touched; int *f_slide;
   float *nql; double *ncenter; double *njour;
@@ -95,6 +97,8 @@ struct MapView {
   double *fx;   // [3][cap_fix]
   double *fvar; // [9][cap_fix]
   int *fnode;
+  int *fb_base, *fb_len, *fb_next;   // [cap_fix] block table of the pool (a block has >= 1 point)
+  int *sval_b;  // [max_pts] sort values out where the destination is not a slot's perm (fixed-point insertion)
   int *cnt;     // counters [CNT_N]
   double *poses;  // [W][12]
 };
@@ -191,6 +195,7 @@ __device__ __forceinline__ void init_node(const MapView &m, int W, int id, unsig
                                           double cx, double cy, double cz, float ql) {
   const size_t cp = (size_t)m.cap;
   for (int sl = 0; sl < W; sl++) { m.nseg_a[(size_t)sl * cp + id] = 0; m.nseg_b[(size_t)sl * cp + id] = 0; }   // (a recycled id must not inherit segments)
+  m.nfb_head[id] = -1; m.nfb_tail[id] = -1;
   m.nkey[id] = key; m.nroot[id] = root; m.nparent[id] = parent; m.nchild[id] = -1; m.npath[id] = path; m.nopt[id] = -1; m.nlast[id] = 0;
   m.nstamp[id] = 0; m.nsplit[id] = 0; m.ntake[id] = 0; m.nclear[id] = 0; m.ndead[id] = 0;
   m.nlayer[id] = (signed char)layer; m.nstate[id] = 0;
@@ -414,22 +419,100 @@ __global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, in
 }
 
 // Fixed points (VM:2108-2152): new root -> push_fix_novar on the root; else allocate_fix (descend while layer < max_layer).
-__global__ void k_fix_accum(MapView m, MapParams P, int base, int n) {
+// Same order-preserving scheme as the window scans: leaf per point, stable sort by leaf, one wave per leaf.  The points of a leaf
+// become ONE BLOCK of consecutive pool entries (in call order) that joins the leaf's chain: point_fix of the reference.
+__global__ void k_fix_leaf(MapView m, MapParams P, int base, int n) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const size_t cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
+  const size_t cf = (size_t)m.cap_fix;
   const int q = base + p;
-  m.fnode[q] = -1;
   const int h = m.phash[p];
-  if (h < 0) return;
-  int node = m.hvals[h];
-  if (node < 0) return;
-  const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
-  while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
-  atomic_cluster_add(m.nfix + node, cp, x, y, z);   // pcr_fix.push  VM:1174
-  atomic_cluster_add(m.nadd + node, cp, x, y, z);   // pcr_add.push  VM:1176
-  m.f_touched[node] = 1;
-  if (m.nlayer[node] < P.max_layer) m.fnode[q] = node;  // point_fix.push_back only below max_layer (VM:1171-1172)
+  int node = h >= 0 ? m.hvals[h] : -1;
+  if (node >= 0) {
+    const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
+    while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+  }
+  m.skey_a[p] = node >= 0 ? (unsigned int)node : 0xFFFFFFFFu;
+  m.sval_a[p] = p;
+}
+__global__ __launch_bounds__(256) void k_fix_heads(MapView m, int n) {       // work list = start positions of the leaf groups
+  __shared__ int wbase[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool head = false;
+  if (i < n) {
+    const unsigned int key = m.skey_b[i];
+    head = key != 0xFFFFFFFFu && ((i == 0) || m.skey_b[i - 1] != key);
+  }
+  const unsigned long long mask = __ballot(head);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int b0 = tot ? atomicAdd(&m.cnt[CNT_WL], tot) : 0;
+    for (int w = 0; w < 4; w++) wbase[w] += b0;
+  }
+  __syncthreads();
+  if (head) m.wl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+}
+// link block [qb, qb + len) to the end of leaf's chain (one lane; a leaf is served by one wave per call)
+__device__ __forceinline__ void fix_chain_append(const MapView &m, int leaf, int qb, int len) {
+  const int blk = atomicAdd(&m.cnt[CNT_FBLK], 1);
+  if (blk >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; return; }
+  m.fb_base[blk] = qb; m.fb_len[blk] = len; m.fb_next[blk] = -1;
+  const int tail = m.nfb_tail[leaf];
+  if (tail < 0) m.nfb_head[leaf] = blk; else m.fb_next[tail] = blk;
+  m.nfb_tail[leaf] = blk;
+}
+// one wave per leaf group: push_fix_novar VM:1168-1178 for the group's points in call order; pts = the caller's [n][3] array
+__global__ __launch_bounds__(64) void k_fix_accum_ord(MapView m, MapParams P, int base, int n, const double *__restrict__ pts) {
+  __shared__ double T[64 * 9];
+  const int lane = threadIdx.x;
+  const int nseg = m.cnt[CNT_WL];
+  const size_t cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
+  for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const int start = m.wl[s];
+    const int leaf = (int)m.skey_b[start];
+    int end = start;                               // the group ends where the key changes
+    while (true) {
+      const int i = end + lane;
+      const bool same = i < n && (int)m.skey_b[i] == leaf;
+      const unsigned long long mk = __ballot(same);
+      if (mk == ~0ull) { end += 64; continue; }
+      end += __ffsll((long long)~mk) - 1;
+      break;
+    }
+    const bool store = m.nlayer[leaf] < P.max_layer;     // point_fix.push_back only below max_layer  VM:1171-1172
+    double *tgt = lane < 9 ? m.nfix + (size_t)lane * cp : m.nadd + (size_t)(lane - 9) * cp;
+    double acc = lane < 18 ? tgt[leaf] : 0.0;
+    for (int c0 = start; c0 < end; c0 += 64) {
+      const int i = c0 + lane;
+      if (i < end) {
+        const int p = m.sval_b[i];
+        const double x = pts[(size_t)p * 3], y = pts[(size_t)p * 3 + 1], z = pts[(size_t)p * 3 + 2];
+        const int q = base + i;                      // pool entries in GROUP order: the group is one block
+        m.fx[q] = x; m.fx[cf + q] = y; m.fx[2 * cf + q] = z;
+        m.fnode[q] = store ? leaf : -1;
+        double *t = T + lane * 9;
+        t[0] = x * x; t[1] = x * y; t[2] = x * z; t[3] = y * y; t[4] = y * z; t[5] = z * z; t[6] = x; t[7] = y; t[8] = z;
+      }
+      __syncthreads();
+      const int cnt = end - c0 < 64 ? end - c0 : 64;
+      if (lane < 18) {
+        const int k = lane < 9 ? lane : lane - 9;    // pcr_fix.push(pnt) and pcr_add.push(pnt): the same terms, two chains
+        for (int j = 0; j < cnt; j++) acc += T[j * 9 + k];
+      }
+      __syncthreads();
+    }
+    if (lane < 18) tgt[leaf] = acc;
+    if (lane == 63) {
+      const double dn = (double)(end - start);
+      m.nfix[(size_t)9 * cp + leaf] += dn; m.nadd[(size_t)9 * cp + leaf] += dn;
+      m.f_touched[leaf] = 1;
+      if (store) fix_chain_append(m, leaf, base + start, end - start);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ K2: recut
@@ -508,21 +591,68 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
 // are then served one after the other: lane k adds term k of the child's points, in order, to the child's scalar k (kept in LDS
 // between chunks).  The children were created empty by this level's k_recut_leaf, so every chain starts from zero like a new OctoTree.
 template <bool HAS_VAR>
-__global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int win_count) {
+__global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int win_count, int child_layer) {
   using C = OrdCfg<HAS_VAR>;
   __shared__ double T[64 * C::TS];
   __shared__ double A[8 * 64];          // child accumulators: [0..8] body cluster of the current frame, [9..17] pcr_add, [18..62] cov_add
   __shared__ int cj[64];
-  __shared__ int nw[8], nb[8];          // points per child: whole window / current frame
+  __shared__ int nw[8], nb[8], nf[8];   // points per child: window points so far / current frame / fixed points
   const int lane = threadIdx.x;
   const int nsplit = m.cnt[CNT_SPLIT];
-  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
   for (int s = blockIdx.x; s < nsplit; s += gridDim.x) {
     const int X = m.nsl[s];
     const int base = m.nchild[X];
 #pragma unroll
     for (int c = 0; c < 8; c++) A[c * 64 + lane] = 0.0;
-    if (lane < 8) nw[lane] = 0;
+    if (lane < 8) { nw[lane] = 0; nf[lane] = 0; }
+    __syncthreads();
+    // ---- fix_divide (VM:1270-1299) + push_fix (VM:1149-1162): X's fixed points in point_fix order = the chains of X's ancestors
+    //      (blocks that arrived while the ancestor was the leaf), oldest ancestor first, then X's own chain; entries with fnode == X
+    if (m.nfix[(size_t)9 * cp + X] != 0.0) {               // VM:1433: if (pcr_fix.N != 0)
+      int path[8], np = 0;
+      for (int a = X; a >= 0 && np < 8; a = m.nparent[a]) path[np++] = a;
+      for (int pi = np - 1; pi >= 0; pi--) {
+        for (int blk = m.nfb_head[path[pi]]; blk >= 0; blk = m.fb_next[blk]) {
+          const int qb = m.fb_base[blk], qe = qb + m.fb_len[blk];
+          for (int c0 = qb; c0 < qe; c0 += 64) {
+            const int q = c0 + lane;
+            int child = -1;
+            if (q < qe && m.fnode[q] == X) {
+              const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
+              double var[9];
+              if (HAS_VAR) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)k * cf + q];
+              }
+              child = octant_of(m, X, x, y, z);
+              ord_terms<HAS_VAR>(T + lane * C::TS, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
+              m.fnode[q] = (child_layer < P.max_layer) ? base + child : -1;          // VM:1152-1153
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int c = 0; c < 8; c++) {
+              unsigned long long mk = __ballot(child == c);
+              if (mk == 0ull) continue;
+              if (lane == 63) nf[c] += __popcll(mk);
+              if (lane >= 9 && lane < C::NT) {
+                double acc = A[c * 64 + lane];
+                while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * C::TS + lane]; }
+                A[c * 64 + lane] = acc;
+              }
+            }
+            __syncthreads();
+          }
+        }
+      }
+      // pcr_fix of the children = the state of the pcr_add chains after the fixed points
+#pragma unroll 1
+      for (int c = 0; c < 8; c++) {
+        if (nf[c] == 0) continue;
+        if (lane >= 9 && lane < 18) m.nfix[(size_t)(lane - 9) * cp + base + c] = A[c * 64 + lane];
+        if (lane == 63) m.nfix[(size_t)9 * cp + base + c] = (double)nf[c];
+      }
+    }
     for (int fi = 0; fi < win_count; fi++) {
       const int slot = P.mp[fi];
       int anc = X;                       // the node that was the leaf when this slot's scan was inserted
@@ -582,10 +712,14 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
     }
 #pragma unroll 1
     for (int c = 0; c < 8; c++) {
-      if (nw[c] == 0) continue;
+      if (nw[c] + nf[c] == 0) continue;
       const int ch = base + c;
       if (lane >= 9 && lane < C::NT) ord_target(m, P.W, 0, lane)[ch] = A[c * 64 + lane];
-      if (lane == 63) { m.nadd[(size_t)9 * cp + ch] = (double)nw[c]; m.f_sw[ch] = 1; m.f_exist[ch] = 1; m.f_touched[ch] = 1; }
+      if (lane == 63) {
+        m.nadd[(size_t)9 * cp + ch] = (double)(nw[c] + nf[c]);
+        m.f_touched[ch] = 1;
+        if (nw[c] > 0) { m.f_sw[ch] = 1; m.f_exist[ch] = 1; }     // push attaches a SlideWindow and sets isexist (VM:1110-1125); push_fix does neither
+      }
     }
     __syncthreads();
   }
@@ -723,18 +857,8 @@ __global__ void k_extract_write(MapView m, MapParams P, FactorView f, int nfac) 
 
 // ------------------------------------------------------------------------------------------------ K5: marginalise
 __device__ __forceinline__ void cluster_transform_dev(const double *c /*10*/, const double *R /*12*/, double *o /*10*/) {
-  const double n = c[9], tx = R[9], ty = R[10], tz = R[11];
-  const double rv0 = R[0] * c[6] + R[1] * c[7] + R[2] * c[8], rv1 = R[3] * c[6] + R[4] * c[7] + R[5] * c[8], rv2 = R[6] * c[6] + R[7] * c[7] + R[8] * c[8];
-  const double m00 = R[0] * c[0] + R[1] * c[1] + R[2] * c[2], m01 = R[0] * c[1] + R[1] * c[3] + R[2] * c[4], m02 = R[0] * c[2] + R[1] * c[4] + R[2] * c[5];
-  const double m10 = R[3] * c[0] + R[4] * c[1] + R[5] * c[2], m11 = R[3] * c[1] + R[4] * c[3] + R[5] * c[4], m12 = R[3] * c[2] + R[4] * c[4] + R[5] * c[5];
-  const double m20 = R[6] * c[0] + R[7] * c[1] + R[8] * c[2], m21 = R[6] * c[1] + R[7] * c[3] + R[8] * c[4], m22 = R[6] * c[2] + R[7] * c[4] + R[8] * c[5];
-  o[0] = (m00 * R[0] + m01 * R[1] + m02 * R[2]) + 2.0 * rv0 * tx + n * tx * tx;
-  o[1] = (m10 * R[0] + m11 * R[1] + m12 * R[2]) + (rv1 * tx + rv0 * ty) + n * ty * tx;
-  o[2] = (m20 * R[0] + m21 * R[1] + m22 * R[2]) + (rv2 * tx + rv0 * tz) + n * tz * tx;
-  o[3] = (m10 * R[3] + m11 * R[4] + m12 * R[5]) + 2.0 * rv1 * ty + n * ty * ty;
-  o[4] = (m20 * R[3] + m21 * R[4] + m22 * R[5]) + (rv2 * ty + rv1 * tz) + n * tz * ty;
-  o[5] = (m20 * R[6] + m21 * R[7] + m22 * R[8]) + 2.0 * rv2 * tz + n * tz * tz;
-  o[6] = rv0 + n * tx; o[7] = rv1 + n * ty; o[8] = rv2 + n * tz; o[9] = n;
+  const Cl10 w = cluster_transform_exact(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], R);   // the reference's operation order
+  o[0] = w.p00; o[1] = w.p10; o[2] = w.p20; o[3] = w.p11; o[4] = w.p21; o[5] = w.p22; o[6] = w.v0; o[7] = w.v1; o[8] = w.v2; o[9] = w.n;
 }
 
 // plane_update VM:1344-1388.  nplane layout: center(3) normal(3) radius(1) plane_var(36 row-major)
@@ -806,14 +930,32 @@ __device__ __forceinline__ void plane_update_dev(const MapView &m, int id, const
 }
 
 // One thread per leaf: OctoTree::margi leaf branch VM:1468-1584 with mgsize = 1.
+__device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id);
 __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int win_count, int epoch) {
+  __shared__ int wbase[4];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
-  if (id >= nn) return;
-  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return;        // internal node, or freed storage
-  if (slide_count(m, P) < P.thread_num) return;              // VS:1616-1617
-  if (m.f_slide[m.nroot[id]] == 0) return;
-  if (!m.f_exist[id] || !m.f_sw[id]) return;                // VM:1471-1472
+  const bool take = id < nn && margi_leaf_body(m, P, f, nfac, win_count, epoch, id);
+  // leaves whose oldest frame joins point_fix: the work list of k_margi_take
+  const unsigned long long mask = __ballot(take);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wbase[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
+    const int b0 = tot ? atomicAdd(&m.cnt[CNT_TAKE], tot) : 0;
+    for (int w = 0; w < 4; w++) wbase[w] += b0;
+  }
+  __syncthreads();
+  if (take) m.nsl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = id;
+}
+__device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id) {
+  bool take = false;
+  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return false;        // internal node, or freed storage
+  if (slide_count(m, P) < P.thread_num) return false;              // VS:1616-1617
+  if (m.f_slide[m.nroot[id]] == 0) return false;
+  if (!m.f_exist[id] || !m.f_sw[id]) return false;                // VM:1471-1472
   const size_t cp = (size_t)m.cap, W = (size_t)P.W, vs = (size_t)f.vs;
   double add[10], fix[10], pw0[10], ev[3], U[9], lc[10];
   for (int k = 0; k < 10; k++) fix[k] = m.nfix[(size_t)k * cp + id];
@@ -821,7 +963,7 @@ __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, Fact
   for (int k = 0; k < 9; k++) U[k] = m.nevec[(size_t)k * cp + id];
   for (int k = 0; k < 10; k++) pw0[k] = 0.0;
   const int opt = m.nopt[id];
-  if (opt >= nfac) { m.cnt[CNT_OVERFLOW] = 2; return; }     // VM:1488-1492 "Error: opt_state"
+  if (opt >= nfac) { m.cnt[CNT_OVERFLOW] = 2; return false; }     // VM:1488-1492 "Error: opt_state"
   const int slot0 = P.mp[0];
   if (opt >= 0) {                                           // VM:1495-1509
     for (int k = 0; k < 10; k++) add[k] = f.pcr[(size_t)k * vs + opt];
@@ -863,53 +1005,70 @@ __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, Fact
   if (fix[9] < P.max_points) {                              // VM:1541-1555
     if (pw0[9] != 0.0) {
       for (int k = 0; k < 10; k++) fix[k] += pw0[k];
-      if (m.nlayer[id] < P.max_layer) m.ntake[id] = epoch;  // its frame-0 points move to the fixed pool (k_margi_points)
+      if (m.nlayer[id] < P.max_layer) { m.ntake[id] = epoch; take = true; }  // its frame-0 points move to the fixed pool (k_margi_take)
     }
   } else {                                                  // VM:1556-1566
     if (pw0[9] != 0.0) for (int k = 0; k < 10; k++) add[k] -= pw0[k];
     m.nclear[id] = epoch;                                   // PVec().swap(point_fix)
+    m.nfb_head[id] = -1; m.nfb_tail[id] = -1;               // (entries it owns inside older blocks are released by k_margi_fixclear)
   }
   for (int k = 0; k < 10; k++) { m.nadd[(size_t)k * cp + id] = add[k]; m.nfix[(size_t)k * cp + id] = fix[k]; }
   for (int k = 0; k < 10; k++) m.nlc[((size_t)k * W + slot0) * cp + id] = 0.0;   // VM:1569-1574
   m.f_exist[id] = (fix[9] >= add[9]) ? 0 : 1;               // VM:1577-1580
+  return take;
 }
 
-// Frame-0 points of leaves that still collect fixed points -> pool, in world coordinates (VM:1549-1553); slot cleared.
-// The pool slots are claimed with ONE returning atomic per 1024-point workgroup: returning atomics on one address serialise
-// in L2 at ~10 ns each, and the hardware already merges a wave's lanes into one such operation — one per wave (4096 of them)
-// was the whole 41 us of this kernel.
-__global__ __launch_bounds__(1024) void k_margi_points(MapView m, MapParams P, int epoch, int has_var) {
-  __shared__ int wbase[16];
-  const int p = blockIdx.x * 1024 + threadIdx.x;
-  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cf = (size_t)m.cap_fix;
+// Frame-0 points of leaves that still collect fixed points -> pool, in world coordinates (VM:1549-1553), in the leaf's scan order:
+// one wave per such leaf X.  X's frame-0 points are the entries with pnode == X of the segment slot mp[0] gave to X (or to the ancestor
+// that was the leaf when that scan was inserted).  They become ONE block of consecutive pool entries appended to X's chain, so
+// point_fix of the reference — older blocks first, scan order inside a block — can be replayed in order by the next fix_divide.
+__global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int has_var) {
+  const int lane = threadIdx.x;
+  const int ntake = m.cnt[CNT_TAKE];
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
   const int slot = P.mp[0];
-  int node = -1;
-  bool take = false;
-  if (p < m.max_pts) {
-    int *pn = m.pnode + (size_t)slot * mpz + p;
-    node = *pn;
-    *pn = -1;
-    take = node >= 0 && m.ntake[node] == epoch;
+  const int *perm = m.perm + (size_t)slot * mpz;
+  const int *pnode = m.pnode + (size_t)slot * mpz;
+  for (int s = blockIdx.x; s < ntake; s += gridDim.x) {
+    const int X = m.nsl[s];
+    int anc = X;
+    while (anc >= 0 && m.nseg_b[(size_t)slot * cp + anc] == m.nseg_a[(size_t)slot * cp + anc]) anc = m.nparent[anc];
+    if (anc < 0) continue;
+    const int start = m.nseg_a[(size_t)slot * cp + anc], end = m.nseg_b[(size_t)slot * cp + anc];
+    int count = 0;
+    for (int c0 = start; c0 < end; c0 += 64) {
+      const int i = c0 + lane;
+      count += __popcll(__ballot(i < end && pnode[perm[i < end ? i : start]] == X));
+    }
+    if (count == 0) continue;
+    int qb = 0;
+    if (lane == 0) qb = atomicAdd(&m.cnt[CNT_FIX], count);
+    qb = __shfl(qb, 0, 64);
+    if (qb + count > m.cap_fix) { if (lane == 0) m.cnt[CNT_OVERFLOW] = 3; continue; }
+    int off = 0;
+    for (int c0 = start; c0 < end; c0 += 64) {
+      const int i = c0 + lane;
+      const int p = perm[i < end ? i : start];
+      const bool mine = i < end && pnode[p] == X;
+      const unsigned long long mk = __ballot(mine);
+      if (mine) {
+        const int q = qb + off + __popcll(mk & ((1ull << lane) - 1ull));
+        const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+        double wx, wy, wz;
+        world_point(m.poses, bx, by, bz, wx, wy, wz);                    // pv.pnt = x_buf[0].R * pv.pnt + x_buf[0].p  VM:1551
+        m.fx[q] = wx; m.fx[cf + q] = wy; m.fx[2 * cf + q] = wz;
+        for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.pvar[((size_t)k * W + slot) * mpz + p] : 0.0;
+        m.fnode[q] = X;
+      }
+      off += __popcll(mk);
+    }
+    if (lane == 0) fix_chain_append(m, X, qb, count);
   }
-  const unsigned long long mask = __ballot(take);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wbase[wave] = __popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int w = 0; w < 16; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
-    const int base = tot ? atomicAdd(&m.cnt[CNT_FIX], tot) : 0;
-    for (int w = 0; w < 16; w++) wbase[w] += base;
-  }
-  __syncthreads();
-  if (!take) return;
-  const int q = wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull));
-  if (q >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; return; }
-  const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-  const double *R = m.poses;
-  m.fx[q] = R[0] * bx + R[1] * by + R[2] * bz + R[9]; m.fx[cf + q] = R[3] * bx + R[4] * by + R[5] * bz + R[10]; m.fx[2 * cf + q] = R[6] * bx + R[7] * by + R[8] * bz + R[11];
-  for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.pvar[((size_t)k * W + slot) * mpz + p] : 0.0;
-  m.fnode[q] = node;
+}
+// slot mp[0] is emptied (VM:1569-1574: points[mp[0]].clear())
+__global__ __launch_bounds__(1024) void k_margi_points(MapView m, MapParams P) {
+  const int p = blockIdx.x * 1024 + threadIdx.x;
+  if (p < m.max_pts) m.pnode[(size_t)P.mp[0] * m.max_pts + p] = -1;
 }
 __global__ void k_margi_fixclear(MapView m, int epoch) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1283,6 +1442,7 @@ __global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
   const size_t cf = (size_t)m.cap_fix;
   for (int k = 0; k < 3; k++) m.fx[(size_t)k * cf + base + p] = pts[(size_t)p * 3 + k];
   for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + base + p] = 0.0;   // push_fix_novar: no covariance
+  m.fnode[base + p] = -1;
 }
 
 // ================================================================================================ host side
@@ -1341,7 +1501,7 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
       {(void **)&v.nkey, 8, 1}, {(void **)&v.nroot, 4, 1}, {(void **)&v.nparent, 4, 1}, {(void **)&v.nchild, 4, 1}, {(void **)&v.npath, 4, 1},
       {(void **)&v.nopt, 4, 1}, {(void **)&v.nflist, 4, 1}, {(void **)&v.nfl2, 4, 1}, {(void **)&v.nfkey, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
       {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nfree_root, 4, 1}, {(void **)&v.nfree_blk, 4, 1},
-      {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
+      {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.nfb_head, 4, 1}, {(void **)&v.nfb_tail, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
       {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
       {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, 8, (size_t)10 * W},
@@ -1349,9 +1509,11 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
 }
 inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
   return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1},
-          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.wl, 4, 1}};
+          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}};
 }
-inline std::vector<DevArr> fix_arrays(MapView &v) { return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}}; }
+inline std::vector<DevArr> fix_arrays(MapView &v) {
+  return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}, {(void **)&v.fb_base, 4, 1}, {(void **)&v.fb_len, 4, 1}, {(void **)&v.fb_next, 4, 1}};
+}
 
 // grow a family of [rows][cap] arrays from oldcap to newcap, keeping the first `used` columns; new space zero-filled
 inline int grow_arrays(std::vector<DevArr> arrs, size_t oldcap, size_t newcap, size_t used, hipStream_t st, std::string &err) {
@@ -1505,6 +1667,28 @@ inline int map_global_count(MapStore &s, hipStream_t st, int from, int to, std::
   return VBA_OK;
 }
 
+// rocPRIM scratch for sorting up to max_pts (leaf, point) pairs
+inline int map_sort_reserve(MapStore &s, hipStream_t st, std::string &err) {
+  if (s.sort_tmp_for >= s.v.max_pts) return VBA_OK;
+  size_t need = 0;
+  MAPCHK(sort_pairs_u32(nullptr, need, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.sval_b, (size_t)s.v.max_pts, 32u, st));
+  if (need > s.sort_tmp_bytes) {
+    MAPCHK(hipStreamSynchronize(st));
+    if (s.d_sort_tmp) hipFree(s.d_sort_tmp);
+    s.d_sort_tmp = nullptr; s.sort_tmp_bytes = 0;
+    MAPCHK(hipMalloc(&s.d_sort_tmp, need + 256));
+    s.sort_tmp_bytes = need + 256;
+  }
+  s.sort_tmp_for = s.v.max_pts;
+  return VBA_OK;
+}
+// sort key = node id < cap; "no leaf" = all ones, which must sort behind every id
+inline unsigned int map_key_bits(const MapStore &s) {
+  unsigned int bits = 1;
+  while (bits < 32 && (1ull << bits) <= (unsigned long long)s.v.cap) bits++;
+  return bits;
+}
+
 // cut_voxel / cut_voxel_multi for one scan
 inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, const double *pnt_body, const double *var, const double *pose,
                          bool multi, std::string &err, const double *cov6 = nullptr) {
@@ -1558,27 +1742,14 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0, s.stamp);
   if (multi) { r = map_global_count(s, st, CNT_TOUCH, CNT_TOUCH_G, err); if (r) return r; }   // VM:2044 tests the whole scan's voxel count
   // order-preserving accumulation: leaf of every point -> stable sort by leaf -> segments -> one wave per leaf adds in scan order
-  if (s.sort_tmp_for < s.v.max_pts) {
-    size_t need = 0;
-    MAPCHK(sort_pairs_u32(nullptr, need, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.perm, (size_t)s.v.max_pts, 32u, st));
-    if (need > s.sort_tmp_bytes) {
-      MAPCHK(hipStreamSynchronize(st));
-      if (s.d_sort_tmp) hipFree(s.d_sort_tmp);
-      s.d_sort_tmp = nullptr; s.sort_tmp_bytes = 0;
-      MAPCHK(hipMalloc(&s.d_sort_tmp, need + 256));
-      s.sort_tmp_bytes = need + 256;
-    }
-    s.sort_tmp_for = s.v.max_pts;
-  }
+  r = map_sort_reserve(s, st, err); if (r) return r;
   MAPCHK(hipMemsetAsync(s.v.nseg_a + (size_t)slot * s.v.cap, 0, (size_t)s.v.cap * 4, st));   // the slot's previous occupant is gone
   MAPCHK(hipMemsetAsync(s.v.nseg_b + (size_t)slot * s.v.cap, 0, (size_t)s.v.cap * 4, st));
   r = map_set_counter(s, st, CNT_WL, 0, err); if (r) return r;
   hipLaunchKernelGGL(k_ins_leaf, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0);
   {
-    unsigned int bits = 1;                       // node ids < cap; "no leaf" = all ones, which must sort behind every id
-    while (bits < 32 && (1ull << bits) <= (unsigned long long)s.v.cap) bits++;
     size_t tb = s.sort_tmp_bytes;
-    MAPCHK(sort_pairs_u32(s.d_sort_tmp, tb, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.perm + (size_t)slot * s.v.max_pts, (size_t)n, bits, st));
+    MAPCHK(sort_pairs_u32(s.d_sort_tmp, tb, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.perm + (size_t)slot * s.v.max_pts, (size_t)n, map_key_bits(s), st));
   }
   hipLaunchKernelGGL(k_ins_heads, dim3(nb), dim3(256), 0, st, s.v, slot, n);
   {
@@ -1616,7 +1787,15 @@ inline int map_cut_voxel_fix(MapStore &s, hipStream_t st, int n, const double *p
   r = map_set_counter(s, st, CNT_FIX, base + n, err); if (r) return r;
   hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, base, n, 1, 0);
   hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 1, jour, 0);
-  hipLaunchKernelGGL(k_fix_accum, dim3(nb), dim3(256), 0, st, s.v, P, base, n);
+  r = map_sort_reserve(s, st, err); if (r) return r;
+  r = map_set_counter(s, st, CNT_WL, 0, err); if (r) return r;
+  hipLaunchKernelGGL(k_fix_leaf, dim3(nb), dim3(256), 0, st, s.v, P, base, n);
+  {
+    size_t tb = s.sort_tmp_bytes;
+    MAPCHK(sort_pairs_u32(s.d_sort_tmp, tb, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.sval_b, (size_t)n, map_key_bits(s), st));
+  }
+  hipLaunchKernelGGL(k_fix_heads, dim3(nb), dim3(256), 0, st, s.v, n);
+  hipLaunchKernelGGL(k_fix_accum_ord, dim3(n < 4096 ? n : 4096), dim3(64), 0, st, s.v, P, base, n, d_pts);
   MAPCHK(hipGetLastError());
   r = map_read_counters(s, st, err);
   if (r) return r;
@@ -1651,12 +1830,8 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
         hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_SPLIT, 0);
         hipLaunchKernelGGL(k_recut_leaf, dim3(grid_nodes), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
         if (L < s.opt.max_layer) {
-          if (max_n > 0 && win_count > 0) {      // (before the fixed points: it STORES the children's sums, k_recut_fixpts adds to them)
-            if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(64), 0, st, s.v, P, win_count);
-            else hipLaunchKernelGGL((k_recut_push<false>), dim3(4096), dim3(64), 0, st, s.v, P, win_count);
-          }
-          if (s.h_cnt[CNT_FIX] > 0)
-            hipLaunchKernelGGL(k_recut_fixpts, dim3((s.h_cnt[CNT_FIX] + 255) / 256), dim3(256), 0, st, s.v, P, s.epoch, L + 1);
+          if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(64), 0, st, s.v, P, win_count, L + 1);
+          else hipLaunchKernelGGL((k_recut_push<false>), dim3(4096), dim3(64), 0, st, s.v, P, win_count, L + 1);
         }
       }
       // tras_opt pass 1 rides in the same submission: one counter read-back serves the overflow check and the factor count
@@ -1713,9 +1888,13 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   if (nn == 0) return VBA_OK;
   s.epoch++;
   const dim3 gn((nn + 255) / 256), b(256);
+  hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_TAKE, 0);
   hipLaunchKernelGGL(k_margi_leaf, gn, b, 0, st, s.v, P, f, nfac, win_count, s.epoch);
   if (n_slide_before >= s.opt.thread_num) {
-    if (s.npts[slot0] > 0) hipLaunchKernelGGL(k_margi_points, dim3((s.v.max_pts + 1023) / 1024), dim3(1024), 0, st, s.v, P, s.epoch, s.have_var ? 1 : 0);
+    if (s.npts[slot0] > 0) {
+      hipLaunchKernelGGL(k_margi_take, dim3(4096), dim3(64), 0, st, s.v, P, s.have_var ? 1 : 0);
+      hipLaunchKernelGGL(k_margi_points, dim3((s.v.max_pts + 1023) / 1024), dim3(1024), 0, st, s.v, P);
+    }
     if (s.h_cnt[CNT_FIX] > 0) hipLaunchKernelGGL(k_margi_fixclear, dim3((s.h_cnt[CNT_FIX] + 255) / 256), b, 0, st, s.v, s.epoch);
     for (int L = s.opt.max_layer - 1; L >= 0; L--) hipLaunchKernelGGL(k_margi_up, gn, b, 0, st, s.v, P, L);
     hipLaunchKernelGGL(k_margi_roots, gn, b, 0, st, s.v, P, jour, s.epoch, n_slide_before);
