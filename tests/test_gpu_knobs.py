@@ -15,7 +15,7 @@ path): every LocalBA knob set and every GBA knob set, run through the C ABI agai
 
 Chain per set: var_init -> pvec_update + cut_voxel_multi x W -> multi_recut (+ tras_opt) -> acc_evaluate2 -> Lidar_BA_Optimizer ->
 LI_BA_Optimizer and LI_BA_OptimizerGravity -> multi_margi -> refined planes (centre, normal, radius, plane_var, cov_add).
-Bars: structure exact; sums / H / g / r / planes at the bars of tests/test_gpu_fullsize.py.
+Bars: structure exact; pcr_add / cov_add bit-identical; H / g / r / planes at the bars of tests/test_gpu_fullsize.py.
 """
 import dataclasses
 
@@ -98,8 +98,7 @@ def test_local_mapping_chain_on_shipped_knob_set(oracle, name):
     nplane = _assert_structure_equal(g, o)
     assert nplane >= V and int(o[:, 3].max()) <= wl.max_layer
     assert np.array_equal(g[:, 9] >= 0, o[:, 9] >= 0), "tras_opt selects different leaves"
-    sc = np.maximum(np.abs(oca).max(1), 1e-300)
-    assert (np.abs(gpv[:, 41:] - oca).max(1) <= 1e-9 * sc).all(), "cov_add after insert / recut"
+    assert np.array_equal(gpv[:, 41:], oca), "cov_add after insert / recut is not bit-identical"
 
     # a9 / a10 at the start poses
     H, gr, r = ctx.acc_evaluate2(poses)
@@ -151,9 +150,8 @@ def test_local_mapping_chain_on_shipped_knob_set(oracle, name):
     sc = np.abs(O).reshape(len(O), -1).max(1)
     err = np.abs(G - O).reshape(len(O), -1).max(1)
     assert (err <= 1e-5 * sc + 1e-18).all(), ("plane_var", float((err / np.maximum(sc, 1e-300)).max()))
-    assert np.quantile(err / np.maximum(sc, 1e-300), 0.99) < 5e-8
-    sc = np.maximum(np.abs(oca).max(1), 1e-300)
-    assert (np.abs(gpv[:, 41:] - oca).max(1) <= 1e-9 * sc).all(), "cov_add after margi"
+    assert np.quantile(err / np.maximum(sc, 1e-300), 0.99) < 1e-8
+    assert np.array_equal(gpv[:, 41:], oca), "cov_add after margi is not bit-identical"
     # the next scan of the session lands on the marginalised map: ring rotation + one more insert / recut (VS:2014-2019, 1916-1927)
     ctx.slide(1); om.slide(1)
     x2 = np.concatenate([refined[1:], refined[-1:]])
