@@ -55,6 +55,7 @@ __host__ __device__ inline long long key_axis(double pw, double voxel_size) {
 enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CNT_FACTORS, CNT_NEWSLOTS, CNT_LEAVES, CNT_BADKEY, CNT_SNAP,
        CNT_USED, CNT_FREE_ROOTS, CNT_FREE_BLOCKS,
        CNT_FBLK, CNT_TAKE,         // blocks of the fixed-point pool / leaves whose oldest frame moves to the pool in this margi
+       CNT_WLB, CNT_CURSOR,        // leaves of the work list with more than 64 points of the scan (their own kernel) / segment allocator of the scan
        CNT_WL, CNT_SPLIT,          // ordered accumulation: leaf segments of the scan being inserted / leaves split by the current recut level
        CNT_SLIDE_G, CNT_TOUCH_G,   // the two counts the reference's 'fewer voxels than threads' quirks test, summed over the ranks when the map is sharded
        CNT_N };
@@ -75,6 +76,7 @@ struct MapView {
   unsigned long long *nkey; int *nroot; int *nparent; int *nchild; int *npath; int *nopt; int *nflist /* factor index -> leaf (tras_opt order) */; int *nfl2 /* the same before the occupancy sort */; unsigned int *nfkey; int *fhist /* [EXTRACT_NB_MAX] */; int *nlast; int *nstamp; int *nsplit; int *ntake; int *nclear; int *ndead;
   int *nfree_root, *nfree_blk;   // stacks of recycled node ids: single root nodes / bases of 8-node child blocks (map_prune)
   int *nseg_a, *nseg_b;          // [W][cap]: the points a scan slot gave to a leaf AT INSERTION = perm[slot][nseg_a .. nseg_b) (scan order)
+  int *ncnt;                     // [cap] points of the scan being inserted per leaf, then the scatter cursor; zero between inserts
   int *nsl;                      // [cap] leaves split by the current recut level (margi: leaves whose oldest frame joins the fixed points)
   int *nfb_head, *nfb_tail;      // [cap] a leaf's fixed points (point_fix) arrive in BLOCKS of consecutive pool entries; the blocks are chained in arrival order
   signed char *nlayer; signed char *nstate;
@@ -92,6 +94,8 @@ struct MapView {
   unsigned int *skey_a, *skey_b;   // [max_pts] sort keys (leaf id) in / out
   int *sval_a;  // [max_pts] sort values in (the point index)
   int *wl;      // [max_pts] leaves that received points of the scan being inserted
+  int *wlb;     // [max_pts] those with more than 64 points
+  int4 *wl4;    // [max_pts] work list entries (leaf, segment start, points, -) for the per-leaf kernels: one 16-byte load
   // fixed-point pool
   int cap_fix;
   double *fx;   // [3][cap_fix]
@@ -194,7 +198,7 @@ __device__ __forceinline__ int octant_of(const MapView &m, int node, double x, d
 __device__ __forceinline__ void init_node(const MapView &m, int W, int id, unsigned long long key, int root, int parent, int layer, int path,
                                           double cx, double cy, double cz, float ql) {
   const size_t cp = (size_t)m.cap;
-  for (int sl = 0; sl < W; sl++) { m.nseg_a[(size_t)sl * cp + id] = 0; m.nseg_b[(size_t)sl * cp + id] = 0; }   // (a recycled id must not inherit segments)
+  // (nseg_a / nseg_b of a fresh id are zero: node storage is zero-filled at allocation and k_prune_zero clears what it recycles)
   m.nfb_head[id] = -1; m.nfb_tail[id] = -1;
   m.nkey[id] = key; m.nroot[id] = root; m.nparent[id] = parent; m.nchild[id] = -1; m.npath[id] = path; m.nopt[id] = -1; m.nlast[id] = 0;
   m.nstamp[id] = 0; m.nsplit[id] = 0; m.ntake[id] = 0; m.nclear[id] = 0; m.ndead[id] = 0;
@@ -226,6 +230,10 @@ __global__ void k_f64_to_cnt(const double *in, int *cnt, int which) { cnt[which]
 // Phase 1: world transform, key, find-or-claim the hash slot of the root voxel.
 __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int slot, int n, int world_given, int stamp) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!world_given) {   // the slot's previous occupant is gone: its insertion segments are cleared here (k_ins_scan writes the new ones)
+    int *sa = m.nseg_a + (size_t)slot * m.cap, *sb = m.nseg_b + (size_t)slot * m.cap;
+    for (int i = p; i < m.cap; i += gridDim.x * blockDim.x) { sa[i] = 0; sb[i] = 0; }
+  }
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
   int hslot = -1, root = -1;
   if (p < n) {
@@ -325,43 +333,30 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, 
   atomicAdd(&m.cnt[CNT_ROOTS], 1);
 }
 
-// Phase 3: descend to the leaf (OctoTree::allocate VM:1204-1237); the leaf id is the sort key of the point.
+// Phase 3: descend to the leaf (OctoTree::allocate VM:1204-1237) and count the leaf's points; the first point of a leaf puts it on
+// the work list.  Grouping by leaf needs no global sort: count -> exclusive scan over the touched leaves (their segments of perm,
+// in any order) -> scatter (arrival order inside a segment) -> the wave that owns the leaf puts its segment into scan order.
 __global__ __launch_bounds__(256) void k_ins_leaf(MapView m, MapParams P, int slot, int n, int multi) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
-  const bool dropped = multi && touch_count(m, P) < P.thread_num;   // VM:2044-2045: the scan is dropped
-  const int h = m.phash[p];
-  int node = (!dropped && h >= 0) ? m.hvals[h] : -1;
-  if (node >= 0) {
-    const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-    double x, y, z;
-    world_point(m.poses, bx, by, bz, x, y, z);
-    while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
-    m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1;
-  }
-  m.pnode[(size_t)slot * mpz + p] = node;
-  m.skey_a[p] = node >= 0 ? (unsigned int)node : 0xFFFFFFFFu;
-  m.sval_a[p] = p;
-}
-
-// Phase 4 (after the stable sort by leaf): group boundaries -> the leaf's segment [nseg_a, nseg_b) of perm[slot]; the leaf joins the work list.
-__global__ __launch_bounds__(256) void k_ins_heads(MapView m, int slot, int n) {
   __shared__ int wbase[4];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t cp = (size_t)m.cap;
-  unsigned int key = 0xFFFFFFFFu;
-  bool head = false;
-  if (i < n) {
-    key = m.skey_b[i];
-    if (key != 0xFFFFFFFFu) {
-      head = (i == 0) || m.skey_b[i - 1] != key;
-      const bool tail = (i == n - 1) || m.skey_b[i + 1] != key;
-      if (head) m.nseg_a[(size_t)slot * cp + key] = i;
-      if (tail) m.nseg_b[(size_t)slot * cp + key] = i + 1;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
+  bool first = false;
+  int node = -1;
+  if (p < n) {
+    const bool dropped = multi && touch_count(m, P) < P.thread_num;   // VM:2044-2045: the scan is dropped
+    const int h = m.phash[p];
+    node = (!dropped && h >= 0) ? m.hvals[h] : -1;
+    if (node >= 0) {
+      const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+      double x, y, z;
+      world_point(m.poses, bx, by, bz, x, y, z);
+      while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+      first = atomicAdd(&m.ncnt[node], 1) == 0;
+      if (first) { m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1; }
     }
+    m.pnode[(size_t)slot * mpz + p] = node;
   }
-  const unsigned long long mask = __ballot(head);
+  const unsigned long long mask = __ballot(first);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wbase[wave] = __popcll(mask);
   __syncthreads();
@@ -372,49 +367,192 @@ __global__ __launch_bounds__(256) void k_ins_heads(MapView m, int slot, int n) {
     for (int w = 0; w < 4; w++) wbase[w] += base;
   }
   __syncthreads();
-  if (head) m.wl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)key;   // (the order of the list carries no meaning)
+  if (first) m.wl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = node;   // (the order of the list carries no meaning)
 }
 
-// Phase 5: one wave per leaf of the work list — push VM:1129-1140 for the leaf's points in scan order.
+// Phase 4: every leaf of the work list gets its segment [nseg_a, nseg_b) of perm[slot].  The ORDER of the segments carries no meaning,
+// so no global scan is needed: a workgroup scans its 256 counts and reserves their sum with one atomic on the scan's cursor.
+// ncnt becomes the scatter cursor; leaves with more than 64 points also go onto the list of the workgroup-per-leaf kernel.
+__global__ __launch_bounds__(256) void k_ins_scan(MapView m, int slot) {
+  __shared__ int wsum[4];
+  __shared__ int sbase;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int T = m.cnt[CNT_WL];
+  if (blockIdx.x * blockDim.x >= T) return;                  // (the grid covers the scan's points, an upper bound of T)
+  const size_t cp = (size_t)m.cap;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int leaf = i < T ? m.wl[i] : -1;
+  const int c = leaf >= 0 ? m.ncnt[leaf] : 0;
+  int incl = c;
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    sbase = atomicAdd(&m.cnt[CNT_CURSOR], tot);
+  }
+  __syncthreads();
+  int wb = sbase;
+  for (int w = 0; w < wave; w++) wb += wsum[w];
+  if (leaf >= 0) {
+    const int start = wb + incl - c;
+    m.nseg_a[(size_t)slot * cp + leaf] = start;
+    m.nseg_b[(size_t)slot * cp + leaf] = start + c;
+    m.ncnt[leaf] = start;
+    m.wl4[i] = make_int4(leaf, start, c, 0);
+    if (c > 64) m.wlb[atomicAdd(&m.cnt[CNT_WLB], 1)] = i;   // (few)
+  }
+}
+
+// Phase 5: every point takes the next free place of its leaf's segment (arrival order; the owner of the leaf orders the segment)
+__global__ __launch_bounds__(256) void k_ins_scatter(MapView m, int slot, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts;
+  const int node = m.pnode[(size_t)slot * mpz + p];
+  if (node >= 0) m.perm[(size_t)slot * mpz + atomicAdd(&m.ncnt[node], 1)] = p;
+}
+
+// one chunk of <= 64 points of a leaf in scan order: lane j prepares the terms of point j, lane k adds term k of the points in order.
+// The terms are staged in two rounds of <= 32 (the LDS image of all 63 would hold a CU to 4 waves).
+template <bool HAS_VAR>
+__device__ __forceinline__ void ord_chunk(const MapView &m, const MapParams &P, int slot, int p, int cnt, int lane, double *T, double &acc) {
+  using C = OrdCfg<HAS_VAR>;
+  constexpr int NR = HAS_VAR ? 2 : 1, RT = HAS_VAR ? 32 : 18, TS = RT | 1;
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
+  double t[C::NT];
+  if (lane < cnt) {
+    const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+    double var[9];
+    if (HAS_VAR) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+    }
+    double x, y, z;
+    world_point(m.poses, bx, by, bz, x, y, z);
+    ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    if (lane < cnt) {
+#pragma unroll
+      for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) T[lane * TS + k] = t[r * RT + k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (lane >= r * RT && lane < (r + 1) * RT && lane < C::NT)
+      for (int j = 0; j < cnt; j++) acc += T[j * TS + (lane - r * RT)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Phase 6: one wave per leaf of the work list with <= 64 points — push VM:1129-1140 for the leaf's points in scan order.  The
+// segment arrives in arrival order; a point's place in scan order is the number of smaller indices in the segment (64 lane reads).
 template <bool HAS_VAR>
 __global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, int slot) {
   using C = OrdCfg<HAS_VAR>;
-  __shared__ double T[64 * C::TS];
+  constexpr int TS = (HAS_VAR ? 32 : 18) | 1;
+  __shared__ double T[64 * TS];
+  __shared__ int sp[64];
   const int lane = threadIdx.x;
   const int nseg = m.cnt[CNT_WL];
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
-  const int *perm = m.perm + (size_t)slot * mpz;
+  int *perm = m.perm + (size_t)slot * mpz;
   double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0);
   for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
-    const int leaf = m.wl[s];
-    const int start = m.nseg_a[(size_t)slot * cp + leaf], end = m.nseg_b[(size_t)slot * cp + leaf];
+    const int4 e = m.wl4[s];
+    const int leaf = e.x, start = e.y, cnt = e.z;
+    if (cnt > 64) continue;                              // k_ins_accum_big
     double acc = lane < C::NT ? tgt[leaf] : 0.0;
-    for (int c0 = start; c0 < end; c0 += 64) {
-      const int i = c0 + lane;
-      if (i < end) {
-        const int p = perm[i];
-        const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-        double var[9];
-        if (HAS_VAR) {
-#pragma unroll
-          for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
-        }
-        double x, y, z;
-        world_point(m.poses, bx, by, bz, x, y, z);
-        ord_terms<HAS_VAR>(T + lane * C::TS, bx, by, bz, x, y, z, var);
+    const int pa = lane < cnt ? perm[start + lane] : 0x7FFFFFFF;
+    int rank = 0;
+    for (int i = 0; i < cnt; i++) rank += (__shfl(pa, i, 64) < pa) ? 1 : 0;
+    if (lane < cnt) { sp[rank] = pa; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    const int p = lane < cnt ? sp[lane] : 0;
+    if (lane < cnt) perm[start + lane] = p;              // the segment in scan order (recut / margi read it again)
+    ord_chunk<HAS_VAR>(m, P, slot, p, cnt, lane, T, acc);
+    if (lane < C::NT) tgt[leaf] = acc;
+    if (lane == 63) {                                    // N of both clusters: integers, exact in f64
+      m.nlc[((size_t)9 * W + slot) * cp + leaf] += (double)cnt;
+      m.nadd[(size_t)9 * cp + leaf] += (double)cnt;
+      m.ncnt[leaf] = 0;
+    }
+  }
+}
+
+// Leaves with more than 64 points of the scan: one workgroup per leaf.  Scan order from a BITMAP of the scan's point indices in LDS
+// (set the bits of the segment's points, count the bits below each set bit): O(n / 64 + points) whatever the segment size; scans of
+// more than `win` points are covered window by window.  Wave 0 then runs the chains chunk by chunk.
+template <bool HAS_VAR>
+__global__ __launch_bounds__(256) void k_ins_accum_big(MapView m, MapParams P, int slot, int n, int win) {
+  using C = OrdCfg<HAS_VAR>;
+  constexpr int TS = (HAS_VAR ? 32 : 18) | 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bm[];     // [win / 64] bitmap, then [win / 64] int prefix, then T
+  const int nw = win / 64;
+  int *pre = (int *)(bm + nw);
+  double *T = (double *)(pre + nw + 2);
+  __shared__ int wsum[4];
+  __shared__ int sbase;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbig = m.cnt[CNT_WLB];
+  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
+  int *perm = m.perm + (size_t)slot * mpz;
+  for (int s = blockIdx.x; s < nbig; s += gridDim.x) {
+    const int4 e = m.wl4[m.wlb[s]];
+    const int leaf = e.x, start = e.y, cnt = e.z;
+    // ---- order the segment: its points' indices are distinct integers in [0, n)
+    int written = 0;
+    for (int w0 = 0; w0 < n; w0 += win) {
+      for (int i = tid; i < nw; i += 256) bm[i] = 0ull;
+      __syncthreads();
+      for (int i = tid; i < cnt; i += 256) {
+        const int p = perm[start + i] - w0;
+        if (p >= 0 && p < win) atomicOr(&bm[p >> 6], 1ull << (p & 63));
       }
       __syncthreads();
-      const int cnt = end - c0 < 64 ? end - c0 : 64;
-      if (lane < C::NT)
-        for (int j = 0; j < cnt; j++) acc += T[j * C::TS + lane];
+      // exclusive prefix of the word popcounts
+      int loc = 0;
+      const int per = (nw + 255) / 256;
+      for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i < nw) loc += __popcll(bm[i]); }
+      int incl = loc;
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int wb = 0;
+      for (int w = 0; w < wave; w++) wb += wsum[w];
+      int run = wb + incl - loc;
+      for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i < nw) { pre[i] = run; run += __popcll(bm[i]); } }
+      if (tid == 255) sbase = run;
+      __syncthreads();
+      // (the ordered indices go to sval_b first: perm still holds unread arrival-order entries of later windows)
+      for (int i = tid; i < nw; i += 256) {
+        unsigned long long b = bm[i];
+        int o = pre[i];
+        while (b) { const int j = __ffsll((long long)b) - 1; b &= b - 1; m.sval_b[start + written + o++] = w0 + i * 64 + j; }
+      }
+      __syncthreads();
+      written += sbase;
       __syncthreads();
     }
-    if (lane < C::NT) tgt[leaf] = acc;
-    if (lane == 63) {                                   // N of both clusters: integers, exact in f64
-      const double dn = (double)(end - start);
-      m.nlc[((size_t)9 * W + slot) * cp + leaf] += dn;
-      m.nadd[(size_t)9 * cp + leaf] += dn;
+    for (int i = tid; i < cnt; i += 256) perm[start + i] = m.sval_b[start + i];
+    __syncthreads();
+    // ---- the chains (wave 0)
+    if (wave == 0) {
+      double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0);
+      double acc = lane < C::NT ? tgt[leaf] : 0.0;
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int cc = cnt - c0 < 64 ? cnt - c0 : 64;
+        const int p = lane < cc ? perm[start + c0 + lane] : 0;
+        ord_chunk<HAS_VAR>(m, P, slot, p, cc, lane, T, acc);
+      }
+      if (lane < C::NT) tgt[leaf] = acc;
+      if (lane == 63) {
+        m.nlc[((size_t)9 * W + slot) * cp + leaf] += (double)cnt;
+        m.nadd[(size_t)9 * cp + leaf] += (double)cnt;
+        m.ncnt[leaf] = 0;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -593,10 +731,12 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
 template <bool HAS_VAR>
 __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int win_count, int child_layer) {
   using C = OrdCfg<HAS_VAR>;
-  __shared__ double T[64 * C::TS];
+  constexpr int NR = HAS_VAR ? 2 : 1, RT = HAS_VAR ? 32 : 18, TS = RT | 1;    // the terms are staged in rounds of <= 32 (LDS = occupancy here)
+  __shared__ double T[64 * TS];
   __shared__ double A[8 * 64];          // child accumulators: [0..8] body cluster of the current frame, [9..17] pcr_add, [18..62] cov_add
-  __shared__ int cj[64];
-  __shared__ int nw[8], nb[8], nf[8];   // points per child: window points so far / current frame / fixed points
+  __shared__ int fj[64];
+  __shared__ int nw[8], nb[8], nf[8], curf[8];   // per child: window points so far / points of the frame being added / fixed points / that frame
+  __shared__ int fs[VBA_MAX_WIN], flen[VBA_MAX_WIN], foff[VBA_MAX_WIN + 1];   // per frame: start and length of the candidate segment; offsets in the common index space
   const int lane = threadIdx.x;
   const int nsplit = m.cnt[CNT_SPLIT];
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
@@ -618,6 +758,7 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
           for (int c0 = qb; c0 < qe; c0 += 64) {
             const int q = c0 + lane;
             int child = -1;
+            double t[C::NT];
             if (q < qe && m.fnode[q] == X) {
               const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
               double var[9];
@@ -626,22 +767,29 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
                 for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)k * cf + q];
               }
               child = octant_of(m, X, x, y, z);
-              ord_terms<HAS_VAR>(T + lane * C::TS, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
+              ord_terms<HAS_VAR>(t, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
               m.fnode[q] = (child_layer < P.max_layer) ? base + child : -1;          // VM:1152-1153
             }
-            __syncthreads();
-#pragma unroll 1
-            for (int c = 0; c < 8; c++) {
-              unsigned long long mk = __ballot(child == c);
-              if (mk == 0ull) continue;
-              if (lane == 63) nf[c] += __popcll(mk);
-              if (lane >= 9 && lane < C::NT) {
-                double acc = A[c * 64 + lane];
-                while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * C::TS + lane]; }
-                A[c * 64 + lane] = acc;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+              if (child >= 0) {
+#pragma unroll
+                for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) T[lane * TS + k] = t[r * RT + k];
               }
+              __syncthreads();
+#pragma unroll 1
+              for (int c = 0; c < 8; c++) {
+                unsigned long long mk = __ballot(child == c);
+                if (mk == 0ull) continue;
+                if (r == 0 && lane == 63) nf[c] += __popcll(mk);
+                if (lane >= 9 && lane >= r * RT && lane < (r + 1) * RT && lane < C::NT) {
+                  double acc = A[c * 64 + lane];
+                  while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * TS + lane - r * RT]; }
+                  A[c * 64 + lane] = acc;
+                }
+              }
+              __syncthreads();
             }
-            __syncthreads();
           }
         }
       }
@@ -653,63 +801,93 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
         if (lane == 63) m.nfix[(size_t)9 * cp + base + c] = (double)nf[c];
       }
     }
-    for (int fi = 0; fi < win_count; fi++) {
-      const int slot = P.mp[fi];
+    // ---- subdivide (VM:1307-1338): the frames' candidate entries form ONE index space [0, total) in frame order, so short segments
+    //      share a chunk of 64 and the memory trips of the frames overlap instead of following each other
+    if (lane < win_count) {
+      const int slot = P.mp[lane];
       int anc = X;                       // the node that was the leaf when this slot's scan was inserted
       while (anc >= 0 && m.nseg_b[(size_t)slot * cp + anc] == m.nseg_a[(size_t)slot * cp + anc]) anc = m.nparent[anc];
-      if (anc < 0) continue;             // the frame gave X nothing
-      const int start = m.nseg_a[(size_t)slot * cp + anc], end = m.nseg_b[(size_t)slot * cp + anc];
-      const int *perm = m.perm + (size_t)slot * mpz;
-      int *pnode = m.pnode + (size_t)slot * mpz;
-      if (lane < 8) nb[lane] = 0;
-      if (lane < 9) {
+      fs[lane] = anc >= 0 ? m.nseg_a[(size_t)slot * cp + anc] : 0;
+      flen[lane] = anc >= 0 ? m.nseg_b[(size_t)slot * cp + anc] - fs[lane] : 0;
+    }
+    if (lane < 8) { curf[lane] = -1; nb[lane] = 0; }
+    __syncthreads();
+    if (lane == 0) { int o = 0; for (int k = 0; k < win_count; k++) { foff[k] = o; o += flen[k]; } foff[win_count] = o; }
+    __syncthreads();
+    const int total = foff[win_count];
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int tpos = c0 + lane;
+      int child = -1, f = 0;
+      double t[C::NT];
+      if (tpos < total) {
+        while (tpos >= foff[f + 1]) f++;
+        const int slot = P.mp[f];
+        const int p = m.perm[(size_t)slot * mpz + fs[f] + (tpos - foff[f])];
+        if (m.pnode[(size_t)slot * mpz + p] == X) {
+          const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+          double var[9];
+          if (HAS_VAR) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) A[c * 64 + lane] = 0.0;
+            for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+          }
+          double x, y, z;
+          world_point(m.poses + 12 * f, bx, by, bz, x, y, z);
+          child = octant_of(m, X, x, y, z);
+          ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
+          m.pnode[(size_t)slot * mpz + p] = base + child;
+        }
+      }
+      fj[lane] = f;
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+      if (child >= 0) {
+#pragma unroll
+        for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) T[lane * TS + k] = t[r * RT + k];
       }
       __syncthreads();
-      for (int c0 = start; c0 < end; c0 += 64) {
-        const int i = c0 + lane;
-        int child = -1;
-        if (i < end) {
-          const int p = perm[i];
-          if (pnode[p] == X) {
-            const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-            double var[9];
-            if (HAS_VAR) {
-#pragma unroll
-              for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
-            }
-            double x, y, z;
-            world_point(m.poses + 12 * fi, bx, by, bz, x, y, z);
-            child = octant_of(m, X, x, y, z);
-            ord_terms<HAS_VAR>(T + lane * C::TS, bx, by, bz, x, y, z, var);
-            pnode[p] = base + child;
-          }
-        }
-        cj[lane] = child;
-        __syncthreads();
-#pragma unroll 1
-        for (int c = 0; c < 8; c++) {
-          unsigned long long mk = __ballot(child == c);
-          if (mk == 0ull) continue;
-          if (lane == 63) { const int n = __popcll(mk); nw[c] += n; nb[c] += n; }
-          if (lane < C::NT) {
-            double acc = A[c * 64 + lane];
-            while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * C::TS + lane]; }
-            A[c * 64 + lane] = acc;
-          }
-        }
-        __syncthreads();
-      }
-      // the frame's body clusters of the children (pcrs_local[mp[fi]] of each new leaf)
 #pragma unroll 1
       for (int c = 0; c < 8; c++) {
-        if (nb[c] == 0) continue;
-        if (lane < 9) m.nlc[((size_t)lane * W + slot) * cp + base + c] = A[c * 64 + lane];
-        if (lane == 9) m.nlc[((size_t)9 * W + slot) * cp + base + c] = (double)nb[c];
+        const unsigned long long mk0 = __ballot(child == c);
+        if (mk0 == 0ull) continue;
+        if (lane >= 9 && lane >= r * RT && lane < (r + 1) * RT && lane < C::NT) {   // pcr_add / cov_add: one chain through all frames
+          double acc = A[c * 64 + lane];
+          unsigned long long mk = mk0;
+          while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * TS + lane - r * RT]; }
+          A[c * 64 + lane] = acc;
+        }
+        if (r == 0 && (lane < 9 || lane == 63)) {              // pcrs_local: a chain per frame; lane 63 keeps the counts
+          double acc = A[c * 64 + (lane < 9 ? lane : 0)];
+          int cfr = curf[c], cnt = nb[c];
+          unsigned long long mk = mk0;
+          while (mk) {
+            const int j = __ffsll((long long)mk) - 1; mk &= mk - 1;
+            const int fjj = fj[j];
+            if (fjj != cfr) {
+              if (cfr >= 0 && cnt > 0) {
+                if (lane < 9) m.nlc[((size_t)lane * W + P.mp[cfr]) * cp + base + c] = acc;
+                else m.nlc[((size_t)9 * W + P.mp[cfr]) * cp + base + c] = (double)cnt;
+              }
+              acc = 0.0; cnt = 0; cfr = fjj;
+            }
+            if (lane < 9) acc += T[j * TS + lane];
+            cnt++;
+          }
+          if (lane < 9) A[c * 64 + lane] = acc;
+          else { curf[c] = cfr; nb[c] = cnt; nw[c] += __popcll(mk0); }
+        }
       }
       __syncthreads();
+      }
     }
+    // the last frame of every child
+#pragma unroll 1
+    for (int c = 0; c < 8; c++) {
+      const int cfr = curf[c];
+      if (cfr < 0 || nb[c] == 0) continue;
+      if (lane < 9) m.nlc[((size_t)lane * W + P.mp[cfr]) * cp + base + c] = A[c * 64 + lane];
+      if (lane == 9) m.nlc[((size_t)9 * W + P.mp[cfr]) * cp + base + c] = (double)nb[c];
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < 8; c++) {
       if (nw[c] + nf[c] == 0) continue;
@@ -930,32 +1108,50 @@ __device__ __forceinline__ void plane_update_dev(const MapView &m, int id, const
 }
 
 // One thread per leaf: OctoTree::margi leaf branch VM:1468-1584 with mgsize = 1.
-__device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id);
+__device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id);
 __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int win_count, int epoch) {
-  __shared__ int wbase[4];
+  __shared__ int wtake[4], wcnt[4], bases[3];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
-  const bool take = id < nn && margi_leaf_body(m, P, f, nfac, win_count, epoch, id);
-  // leaves whose oldest frame joins point_fix: the work list of k_margi_take
+  // > 0: the leaf's oldest frame (that many points) joins point_fix.  The pool range, the block id and the place on the work list
+  // of k_margi_take are reserved here with ONE returning atomic each per workgroup (per leaf they serialised: ~10 ns each in L2)
+  const int count = id < nn ? margi_leaf_body(m, P, f, nfac, win_count, epoch, id) : 0;
+  const bool take = count > 0;
   const unsigned long long mask = __ballot(take);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wbase[wave] = __popcll(mask);
+  int incl = count;
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  if (lane == 63) wcnt[wave] = incl;
+  if (lane == 0) wtake[wave] = __popcll(mask);
   __syncthreads();
   if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
-    const int b0 = tot ? atomicAdd(&m.cnt[CNT_TAKE], tot) : 0;
-    for (int w = 0; w < 4; w++) wbase[w] += b0;
+    int nt = 0, nc = 0;
+    for (int w = 0; w < 4; w++) { const int a = wtake[w], b = wcnt[w]; wtake[w] = nt; wcnt[w] = nc; nt += a; nc += b; }
+    bases[0] = nt ? atomicAdd(&m.cnt[CNT_TAKE], nt) : 0;
+    bases[1] = nt ? atomicAdd(&m.cnt[CNT_FBLK], nt) : 0;
+    bases[2] = nc ? atomicAdd(&m.cnt[CNT_FIX], nc) : 0;
   }
   __syncthreads();
-  if (take) m.nsl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = id;
+  if (take) {
+    const int r = wtake[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+    const int qb = bases[2] + wcnt[wave] + incl - count;
+    const int blk = bases[1] + r;
+    m.nsl[bases[0] + r] = id; m.wl[bases[0] + r] = qb; m.wlb[bases[0] + r] = count;
+    if (qb + count > m.cap_fix || blk >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; m.wlb[bases[0] + r] = 0; }
+    else {                                                 // link the block to the leaf's chain (this thread owns the leaf)
+      m.fb_base[blk] = qb; m.fb_len[blk] = count; m.fb_next[blk] = -1;
+      const int tail = m.nfb_tail[id];
+      if (tail < 0) m.nfb_head[id] = blk; else m.fb_next[tail] = blk;
+      m.nfb_tail[id] = blk;
+    }
+  }
 }
-__device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id) {
-  bool take = false;
-  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return false;        // internal node, or freed storage
-  if (slide_count(m, P) < P.thread_num) return false;              // VS:1616-1617
-  if (m.f_slide[m.nroot[id]] == 0) return false;
-  if (!m.f_exist[id] || !m.f_sw[id]) return false;                // VM:1471-1472
+__device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id) {
+  int take = 0;
+  if (m.nstate[id] != 0 || m.nlayer[id] < 0) return 0;        // internal node, or freed storage
+  if (slide_count(m, P) < P.thread_num) return 0;              // VS:1616-1617
+  if (m.f_slide[m.nroot[id]] == 0) return 0;
+  if (!m.f_exist[id] || !m.f_sw[id]) return 0;                // VM:1471-1472
   const size_t cp = (size_t)m.cap, W = (size_t)P.W, vs = (size_t)f.vs;
   double add[10], fix[10], pw0[10], ev[3], U[9], lc[10];
   for (int k = 0; k < 10; k++) fix[k] = m.nfix[(size_t)k * cp + id];
@@ -963,7 +1159,7 @@ __device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParam
   for (int k = 0; k < 9; k++) U[k] = m.nevec[(size_t)k * cp + id];
   for (int k = 0; k < 10; k++) pw0[k] = 0.0;
   const int opt = m.nopt[id];
-  if (opt >= nfac) { m.cnt[CNT_OVERFLOW] = 2; return false; }     // VM:1488-1492 "Error: opt_state"
+  if (opt >= nfac) { m.cnt[CNT_OVERFLOW] = 2; return 0; }     // VM:1488-1492 "Error: opt_state"
   const int slot0 = P.mp[0];
   if (opt >= 0) {                                           // VM:1495-1509
     for (int k = 0; k < 10; k++) add[k] = f.pcr[(size_t)k * vs + opt];
@@ -974,21 +1170,17 @@ __device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParam
     if (lc[9] != 0.0) cluster_transform_dev(lc, m.poses, pw0);
   } else {                                                  // VM:1510-1529
     for (int k = 0; k < 10; k++) add[k] = fix[k];
-    double occ[VBA_MAX_WIN_DEV];                             // the N column of every slot first: one memory trip, not one per frame
-#pragma unroll
-    for (int i = 0; i < VBA_MAX_WIN_DEV; i++) occ[i] = (i < win_count) ? m.nlc[((size_t)9 * W + P.mp[i < win_count ? i : 0]) * cp + id] : 0.0;
-#pragma unroll
-    for (int i = 0; i < VBA_MAX_WIN_DEV; i++) {
-      if (i >= win_count || occ[i] == 0.0) continue;
+#pragma unroll 1
+    for (int i = 0; i < win_count; i++) {                    // (rolled: unrolled over 16 frames the exact-order transform cost 255 registers + scratch)
       const int slot = P.mp[i];
+      const double ni = m.nlc[((size_t)9 * W + slot) * cp + id];
+      if (ni == 0.0) continue;
       for (int k = 0; k < 9; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
-      lc[9] = occ[i];
-      {
-        double t[10];
-        cluster_transform_dev(lc, m.poses + 12 * i, t);
-        for (int k = 0; k < 10; k++) add[k] += t[k];
-        if (i == 0) for (int k = 0; k < 10; k++) pw0[k] = t[k];
-      }
+      lc[9] = ni;
+      double t[10];
+      cluster_transform_dev(lc, m.poses + 12 * i, t);
+      for (int k = 0; k < 10; k++) add[k] += t[k];
+      if (i == 0) for (int k = 0; k < 10; k++) pw0[k] = t[k];
     }
     if (m.f_plane[id]) {
       const double N = add[9], b0 = add[6] / N, b1 = add[7] / N, b2 = add[8] / N;
@@ -1005,7 +1197,7 @@ __device__ __forceinline__ bool margi_leaf_body(const MapView &m, const MapParam
   if (fix[9] < P.max_points) {                              // VM:1541-1555
     if (pw0[9] != 0.0) {
       for (int k = 0; k < 10; k++) fix[k] += pw0[k];
-      if (m.nlayer[id] < P.max_layer) { m.ntake[id] = epoch; take = true; }  // its frame-0 points move to the fixed pool (k_margi_take)
+      if (m.nlayer[id] < P.max_layer) { m.ntake[id] = epoch; take = (int)pw0[9]; }  // its frame-0 points (pcrs_local[mp[0]].N of them) move to the fixed pool (k_margi_take)
     }
   } else {                                                  // VM:1556-1566
     if (pw0[9] != 0.0) for (int k = 0; k < 10; k++) add[k] -= pw0[k];
@@ -1030,21 +1222,12 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
   const int *perm = m.perm + (size_t)slot * mpz;
   const int *pnode = m.pnode + (size_t)slot * mpz;
   for (int s = blockIdx.x; s < ntake; s += gridDim.x) {
-    const int X = m.nsl[s];
+    const int X = m.nsl[s], qb = m.wl[s], count = m.wlb[s];      // pool range and chain block were reserved by k_margi_leaf
+    if (count == 0) continue;
     int anc = X;
     while (anc >= 0 && m.nseg_b[(size_t)slot * cp + anc] == m.nseg_a[(size_t)slot * cp + anc]) anc = m.nparent[anc];
     if (anc < 0) continue;
     const int start = m.nseg_a[(size_t)slot * cp + anc], end = m.nseg_b[(size_t)slot * cp + anc];
-    int count = 0;
-    for (int c0 = start; c0 < end; c0 += 64) {
-      const int i = c0 + lane;
-      count += __popcll(__ballot(i < end && pnode[perm[i < end ? i : start]] == X));
-    }
-    if (count == 0) continue;
-    int qb = 0;
-    if (lane == 0) qb = atomicAdd(&m.cnt[CNT_FIX], count);
-    qb = __shfl(qb, 0, 64);
-    if (qb + count > m.cap_fix) { if (lane == 0) m.cnt[CNT_OVERFLOW] = 3; continue; }
     int off = 0;
     for (int c0 = start; c0 < end; c0 += 64) {
       const int i = c0 + lane;
@@ -1052,17 +1235,22 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
       const bool mine = i < end && pnode[p] == X;
       const unsigned long long mk = __ballot(mine);
       if (mine) {
-        const int q = qb + off + __popcll(mk & ((1ull << lane) - 1ull));
-        const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-        double wx, wy, wz;
-        world_point(m.poses, bx, by, bz, wx, wy, wz);                    // pv.pnt = x_buf[0].R * pv.pnt + x_buf[0].p  VM:1551
-        m.fx[q] = wx; m.fx[cf + q] = wy; m.fx[2 * cf + q] = wz;
-        for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.pvar[((size_t)k * W + slot) * mpz + p] : 0.0;
-        m.fnode[q] = X;
+        const int o = off + __popcll(mk & ((1ull << lane) - 1ull));
+        if (o < count) {
+          const int q = qb + o;
+          const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+          double wx, wy, wz;
+          world_point(m.poses, bx, by, bz, wx, wy, wz);                    // pv.pnt = x_buf[0].R * pv.pnt + x_buf[0].p  VM:1551
+          m.fx[q] = wx; m.fx[cf + q] = wy; m.fx[2 * cf + q] = wz;
+          for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.pvar[((size_t)k * W + slot) * mpz + p] : 0.0;
+          m.fnode[q] = X;
+        }
       }
       off += __popcll(mk);
     }
-    if (lane == 0) fix_chain_append(m, X, qb, count);
+    // (a leaf at layer < max_layer keeps every raw point, so the segment holds exactly pcrs_local[mp[0]].N entries of X;
+    //  should it hold fewer, the rest of the reserved range stays unowned)
+    for (int o = off + lane; o < count; o += 64) m.fnode[qb + o] = -1;
   }
 }
 // slot mp[0] is emptied (VM:1569-1574: points[mp[0]].clear())
@@ -1178,7 +1366,7 @@ __global__ void k_prune_zero(MapView m, int W, int epoch) {
   r -= 9;
   if (r < 43) { m.nplane[(size_t)r * cp + id] = 0.0; return; }
   r -= 43;
-  if (r < 10 * W) m.nlc[(size_t)r * cp + id] = 0.0;
+  if (r < 10 * W) { m.nlc[(size_t)r * cp + id] = 0.0; if (r < W) { m.nseg_a[(size_t)r * cp + id] = 0; m.nseg_b[(size_t)r * cp + id] = 0; } }
 }
 __global__ void k_prune_fix(MapView m) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1403,6 +1591,7 @@ __global__ void k_var_init(int n, const double *__restrict__ pin, double *__rest
 __global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, const double *pts, const double *var, const double *pose, const double *cov6) {
 #pragma clang fp contract(off)      // the reference's operation order, separately rounded (cov_add sums these values in order: see ord_terms)
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) { m.cnt[CNT_NEWSLOTS] = 0; m.cnt[CNT_TOUCH] = 0; m.cnt[CNT_WL] = 0; m.cnt[CNT_WLB] = 0; m.cnt[CNT_CURSOR] = 0; }   // the insert's counters (no kernels of their own)
   if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts;
   const double bx = pts[(size_t)p * 3], by = pts[(size_t)p * 3 + 1], bz = pts[(size_t)p * 3 + 2];
@@ -1431,6 +1620,7 @@ __global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, con
 // AoS host layout [n][3] / [n][9] -> the scan slot's SoA arrays
 __global__ void k_scan_to_soa(MapView m, int W, int slot, int n, const double *pts, const double *var) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) { m.cnt[CNT_NEWSLOTS] = 0; m.cnt[CNT_TOUCH] = 0; m.cnt[CNT_WL] = 0; m.cnt[CNT_WLB] = 0; m.cnt[CNT_CURSOR] = 0; }   // the insert's counters (no kernels of their own)
   if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts;
   for (int k = 0; k < 3; k++) m.px[((size_t)k * W + slot) * mpz + p] = pts[(size_t)p * 3 + k];
@@ -1447,6 +1637,7 @@ __global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
 
 // ================================================================================================ host side
 __global__ void k_set_counter(int *cnt, int which, int val) { cnt[which] = val; }
+__global__ void k_recut_prep(int *cnt) { cnt[CNT_SNAP] = cnt[CNT_NODES]; cnt[CNT_SPLIT] = 0; }   // per recut level: node snapshot, empty split list
 __global__ void k_copy_counter(int *cnt, int from, int to) { cnt[to] = cnt[from]; }
 struct DevArr {  // a [rows][cap] device array that can grow its cap keeping [rows][used]
   void **slot; size_t elem, rows;
@@ -1501,7 +1692,7 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
       {(void **)&v.nkey, 8, 1}, {(void **)&v.nroot, 4, 1}, {(void **)&v.nparent, 4, 1}, {(void **)&v.nchild, 4, 1}, {(void **)&v.npath, 4, 1},
       {(void **)&v.nopt, 4, 1}, {(void **)&v.nflist, 4, 1}, {(void **)&v.nfl2, 4, 1}, {(void **)&v.nfkey, 4, 1}, {(void **)&v.nlast, 4, 1}, {(void **)&v.nstamp, 4, 1}, {(void **)&v.nsplit, 4, 1}, {(void **)&v.ntake, 4, 1},
       {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nfree_root, 4, 1}, {(void **)&v.nfree_blk, 4, 1},
-      {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.nfb_head, 4, 1}, {(void **)&v.nfb_tail, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
+      {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.ncnt, 4, 1}, {(void **)&v.nfb_head, 4, 1}, {(void **)&v.nfb_tail, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
       {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
       {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, 8, (size_t)10 * W},
@@ -1509,7 +1700,7 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
 }
 inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
   return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1},
-          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}};
+          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}, {(void **)&v.wlb, 4, 1}, {(void **)&v.wl4, 16, 1}};
 }
 inline std::vector<DevArr> fix_arrays(MapView &v) {
   return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}, {(void **)&v.fb_base, 4, 1}, {(void **)&v.fb_len, 4, 1}, {(void **)&v.fb_next, 4, 1}};
@@ -1735,27 +1926,33 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
     MAPCHK(hipMemsetAsync(s.v.pnode + (size_t)slot * s.v.max_pts + n, 0xFF, (size_t)(s.v.max_pts - n) * 4, st));
   if (cov6 && var) hipLaunchKernelGGL(k_scan_to_soa_pvec_update, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var, s.v.poses, s.v.poses + 16);
   else hipLaunchKernelGGL(k_scan_to_soa, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var);
-  r = map_set_counter(s, st, CNT_NEWSLOTS, 0, err); if (r) return r;
-  r = map_set_counter(s, st, CNT_TOUCH, 0, err); if (r) return r;
   s.stamp++;
   hipLaunchKernelGGL(k_ins_keys, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, 0, s.stamp);
   hipLaunchKernelGGL(k_ins_newroots, dim3(nb), dim3(256), 0, st, s.v, P, 0, 0.0, s.stamp);
   if (multi) { r = map_global_count(s, st, CNT_TOUCH, CNT_TOUCH_G, err); if (r) return r; }   // VM:2044 tests the whole scan's voxel count
-  // order-preserving accumulation: leaf of every point -> stable sort by leaf -> segments -> one wave per leaf adds in scan order
-  r = map_sort_reserve(s, st, err); if (r) return r;
-  MAPCHK(hipMemsetAsync(s.v.nseg_a + (size_t)slot * s.v.cap, 0, (size_t)s.v.cap * 4, st));   // the slot's previous occupant is gone
-  MAPCHK(hipMemsetAsync(s.v.nseg_b + (size_t)slot * s.v.cap, 0, (size_t)s.v.cap * 4, st));
-  r = map_set_counter(s, st, CNT_WL, 0, err); if (r) return r;
+  // order-preserving accumulation: leaf of every point + per-leaf counts -> segments (scan over the touched leaves) -> scatter ->
+  // one wave (workgroup for big leaves) per leaf puts its segment into scan order and adds in that order
   hipLaunchKernelGGL(k_ins_leaf, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0);
+  hipLaunchKernelGGL(k_ins_scan, dim3(nb), dim3(256), 0, st, s.v, slot);
+  hipLaunchKernelGGL(k_ins_scatter, dim3(nb), dim3(256), 0, st, s.v, slot, n);
   {
-    size_t tb = s.sort_tmp_bytes;
-    MAPCHK(sort_pairs_u32(s.d_sort_tmp, tb, s.v.skey_a, s.v.skey_b, s.v.sval_a, s.v.perm + (size_t)slot * s.v.max_pts, (size_t)n, map_key_bits(s), st));
-  }
-  hipLaunchKernelGGL(k_ins_heads, dim3(nb), dim3(256), 0, st, s.v, slot, n);
-  {
-    const int nwg = n < 8192 ? n : 8192;         // one wave per leaf of the work list, grid-stride (the list length stays on the device)
-    if (var) hipLaunchKernelGGL((k_ins_accum_ord<true>), dim3(nwg), dim3(64), 0, st, s.v, P, slot);
-    else hipLaunchKernelGGL((k_ins_accum_ord<false>), dim3(nwg), dim3(64), 0, st, s.v, P, slot);
+    const int nwg = n < 8192 ? n : 8192;         // grid-stride over the work list (its length stays on the device)
+    int win = 128; while (win < n && win < (1 << 19)) win *= 2;         // bitmap window of the big-leaf kernel (<= 96 KB of LDS)
+    const size_t lds_big = (size_t)(win / 64) * 12 + 16 + (size_t)64 * 33 * 8;
+    static bool attr_set[64] = {false};
+    int dev = 0; hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+      hipFuncSetAttribute((const void *)k_ins_accum_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      hipFuncSetAttribute((const void *)k_ins_accum_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      attr_set[dev & 63] = true;
+    }
+    if (var) {
+      hipLaunchKernelGGL((k_ins_accum_ord<true>), dim3(nwg), dim3(64), 0, st, s.v, P, slot);
+      hipLaunchKernelGGL((k_ins_accum_big<true>), dim3(256), dim3(256), lds_big, st, s.v, P, slot, n, win);
+    } else {
+      hipLaunchKernelGGL((k_ins_accum_ord<false>), dim3(nwg), dim3(64), 0, st, s.v, P, slot);
+      hipLaunchKernelGGL((k_ins_accum_big<false>), dim3(256), dim3(256), lds_big, st, s.v, P, slot, n, win);
+    }
   }
   MAPCHK(hipGetLastError());
   // no read-back: capacity was reserved for the worst case (n new roots), so this call cannot overflow
@@ -1826,8 +2023,7 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
     if (s.h_cnt[CNT_NODES] > 0) {
       for (int L = 0; L <= s.opt.max_layer; L++) {
         s.epoch++;
-        hipLaunchKernelGGL(k_copy_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_NODES, (int)CNT_SNAP);
-        hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_SPLIT, 0);
+        hipLaunchKernelGGL(k_recut_prep, dim3(1), dim3(1), 0, st, s.v.cnt);
         hipLaunchKernelGGL(k_recut_leaf, dim3(grid_nodes), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
         if (L < s.opt.max_layer) {
           if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(64), 0, st, s.v, P, win_count, L + 1);
