@@ -490,8 +490,12 @@ class Context:
         non-blocking stream: the sum then races with k_reduce_partials.)"""
         cache = {}
         streams = {}
+        self.collective_calls = 0          # how many exchange steps the library asked for, and how many doubles they carried
+        self.collective_doubles = 0
 
         def hook(ptr, n, stream):
+            self.collective_calls += 1
+            self.collective_doubles += int(n)
             key = (ptr, n)
             if key not in cache:
                 class _Ext:

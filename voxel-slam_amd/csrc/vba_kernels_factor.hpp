@@ -554,15 +554,19 @@ struct SlotLoad {   // everything one (voxel, frame) slot thread reads from HBM
   bool valid;
 };
 
+// `occm` = the voxel's occupancy mask (f.occ[v], requested one step earlier by the caller): the 10 cluster scalars of an EMPTY slot are
+// not read (VM:203-205 `if (sig_orig[i].N != 0)`; 57 % of the slots of the bench window are empty: 8.3 MB of the 23 MB the pass
+// fetched in round 2), the slot then counts as n = 0.
 template <int W>
-__device__ __forceinline__ void slot_load(const FactorView &f, int v, int fi, int end, SlotLoad &q) {
+__device__ __forceinline__ void slot_load(const FactorView &f, int v, int fi, int end, unsigned int occm, SlotLoad &q) {
   const size_t vs = (size_t)f.vs, fs = (size_t)W * vs;
   q.valid = v < end;
   if (q.valid) {
     const double *cp = f.cl + (size_t)fi * vs + v;
-    q.n = cp[9 * fs];
+    const bool on = (occm >> fi) & 1u;
+    q.n = on ? cp[9 * fs] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) q.c[k] = cp[(size_t)k * fs];
+    for (int k = 0; k < 9; k++) q.c[k] = on ? cp[(size_t)k * fs] : 0.0;
     q.coe = f.coe[v];
     q.l0 = f.eigval[v]; q.l1 = f.eigval[vs + v]; q.l2 = f.eigval[2 * vs + v];
     q.NN = f.pcr[9 * vs + v]; q.vs0 = f.pcr[6 * vs + v]; q.vs1 = f.pcr[7 * vs + v]; q.vs2 = f.pcr[8 * vs + v];
@@ -614,6 +618,14 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
     return;
   }
   const int bid = (int)blockIdx.x - (li.dev ? 1 : 0);
+  // A workgroup takes a CONTIGUOUS, balanced range of tiles (round 2 dealt them with stride nwg): its rows of the SoA store are then
+  // 3 TV consecutive voxels per scalar — 576 B at W = 10 — instead of three 192-byte pieces that each straddle a 128-byte line and
+  // share it with a workgroup on another XCD (which fetched it again).
+  const int tile0 = (int)(((long long)bid * ntiles) / nwg), tile1 = (int)(((long long)(bid + 1) * ntiles) / nwg);
+  const int my_vl = threadIdx.x % HessCfg2<W>::TV, my_fi = threadIdx.x / HessCfg2<W>::TV;
+  // the occupancy mask of the first tile's voxel: requested before anything else, it comes back with the prologue's other reads
+  unsigned int occ_nx = 0;
+  if (my_fi < W && tile0 < tile1) { const int v0 = head + tile0 * HessCfg2<W>::TV + my_vl; occ_nx = f.occ[v0 < end ? v0 : end - 1]; }
   __shared__ int lm_dec[2];
   int gate_v = (gate && !lm) ? *gate : 1;     // consumed after the first tile's loads have been requested (one trip, not two)
   double lm_r2 = 0.0;
@@ -655,7 +667,8 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
 
   SlotLoad nx;
   nx.valid = false;
-  if (slot_thread && bid < ntiles) slot_load<W>(f, head + bid * C::TV + vl, fi, end, nx);
+  if (slot_thread && tile0 < tile1) slot_load<W>(f, head + tile0 * C::TV + vl, fi, end, occ_nx, nx);
+  if (slot_thread && tile0 + 1 < tile1) { const int v1 = head + (tile0 + 1) * C::TV + vl; occ_nx = f.occ[v1 < end ? v1 : end - 1]; }   // one tile ahead
   asm volatile("" : "+v"(nx.n));
   if (gate_v == 0) return;                    // uniform
   __syncthreads();
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
   VBA_STAMP(1);
   int stamp_i = 2;
 
-  for (int tile = bid; tile < ntiles; tile += nwg) {
+  for (int tile = tile0; tile < tile1; tile++) {
     // ---------------- phase A (registers of this tile were loaded one iteration ago)
     if (slot_thread) {
       const SlotLoad q = nx;
@@ -751,9 +764,12 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
       }
       if (fi == 0) { cK[3 * vl] = ck1; cK[3 * vl + 1] = ck2; cK[3 * vl + 2] = ck3; }
       // the next tile's loads fly under this tile's contraction
-      const int nt = tile + nwg;
+      const int nt = tile + 1;
       nx.valid = false;
-      if (nt < ntiles) slot_load<W>(f, head + nt * C::TV + vl, fi, end, nx);
+      if (nt < tile1) {
+        slot_load<W>(f, head + nt * C::TV + vl, fi, end, occ_nx, nx);
+        if (nt + 1 < tile1) { const int v2 = head + (nt + 1) * C::TV + vl; occ_nx = f.occ[v2 < end ? v2 : end - 1]; }
+      }
     }
     __syncthreads();
     if (stamp_i < 12) { VBA_STAMP(stamp_i); stamp_i++; }

@@ -183,6 +183,12 @@ __global__ __launch_bounds__(256) void k_lm_solve_m(LmDev *s, const double *__re
   if (stamps) stamps[5] = clock64();
 }
 
+// (Round 3 tried two single-wave forms of this solve for n <= 64 — lane i owns row i, no barriers, no tiles — and measured both slower on
+//  MI355X at n = 60 than the blocked kernel's 24 us: rows in registers with the 1770 updates fully unrolled 31 us (a dependent f64
+//  operation costs ~50 cycles with one wave per SIMD, so the 60 pivot steps are a ~350-cycle chain each: readlane, reciprocal + two
+//  Newton steps, scale, first update), rows in LDS with rolled loops 62 us (every read-modify-write of a row element waits for its
+//  own LDS round trip).  The blocked kernel's panel of 8 columns amortises that chain over 8 pivots.)
+
 // Accept / reject bookkeeping of VM:467-494 (one thread).  r2_dev = the reduced residual of the trial poses.
 // nb > 0: r2 is first summed here from the residual pass' nb workgroup partials (single rank: saves one launch);
 // nb == 0: r2_dev already holds the (all-reduced) scalar.  One wave; every lane takes the (uniform) decision so that the

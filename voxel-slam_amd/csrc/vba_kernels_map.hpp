@@ -108,36 +108,6 @@ struct MapView {
 };
 
 // ------------------------------------------------------------------------------------------------ helpers
-__device__ __forceinline__ void atomic_cluster_add(double *base, size_t fstride, double x, double y, double z) {
-  unsafeAtomicAdd(base + 0 * fstride, x * x); unsafeAtomicAdd(base + 1 * fstride, x * y); unsafeAtomicAdd(base + 2 * fstride, x * z);
-  unsafeAtomicAdd(base + 3 * fstride, y * y); unsafeAtomicAdd(base + 4 * fstride, y * z); unsafeAtomicAdd(base + 5 * fstride, z * z);
-  unsafeAtomicAdd(base + 6 * fstride, x); unsafeAtomicAdd(base + 7 * fstride, y); unsafeAtomicAdd(base + 8 * fstride, z);
-  unsafeAtomicAdd(base + 9 * fstride, 1.0);
-}
-
-// Bf_var (VM:106-121): 9x9 symmetric block [Bi var Bi^T, Bi var; (Bi var)^T, var]; upper triangle (45) added atomically.
-__device__ __forceinline__ void atomic_bfvar_add(double *base, size_t fstride, const double *var, double x, double y, double z) {
-  const double Bi[6][3] = {{2 * x, 0, 0}, {y, x, 0}, {z, 0, x}, {0, 2 * y, 0}, {0, z, y}, {0, 0, 2 * z}};
-  double Bu[6][3];
-#pragma unroll
-  for (int r = 0; r < 6; r++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) Bu[r][c] = Bi[r][0] * var[0 * 3 + c] + Bi[r][1] * var[1 * 3 + c] + Bi[r][2] * var[2 * 3 + c];
-  int idx = 0;
-#pragma unroll
-  for (int r = 0; r < 9; r++)
-#pragma unroll
-    for (int c = r; c < 9; c++) {
-      double val;
-      if (r < 6 && c < 6) val = Bu[r][0] * Bi[c][0] + Bu[r][1] * Bi[c][1] + Bu[r][2] * Bi[c][2];
-      else if (r < 6) val = Bu[r][c - 6];
-      else val = var[(r - 6) * 3 + (c - 6)];
-      if (val != 0.0) unsafeAtomicAdd(base + (size_t)idx * fstride, val);
-      idx++;
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------ order-preserving accumulation
 // The reference pushes a leaf's points one by one in SCAN ORDER (cut_voxel VM:1899-1948 / cut_voxel_multi VM:2061-2095 ->
 // allocate -> push VM:1134-1140): pcrs_local, pcr_add and cov_add are chains  ((s + t_1) + t_2) + ...  of separately rounded
@@ -901,26 +871,6 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
     }
     __syncthreads();
   }
-}
-
-// Fixed points of split leaves -> children (fix_divide VM:1270-1299 + push_fix VM:1149-1162).
-__global__ void k_recut_fixpts(MapView m, MapParams P, int epoch, int child_layer) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nf = m.cnt[CNT_FIX] < m.cap_fix ? m.cnt[CNT_FIX] : m.cap_fix;
-  if (q >= nf) return;
-  const int node = m.fnode[q];
-  if (node < 0 || m.nsplit[node] != epoch) return;
-  const size_t cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
-  const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
-  const int child = m.nchild[node] + octant_of(m, node, x, y, z);
-  atomic_cluster_add(m.nfix + child, cp, x, y, z);
-  atomic_cluster_add(m.nadd + child, cp, x, y, z);
-  double var[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)k * cf + q];
-  atomic_bfvar_add(m.ncov + child, cp, var, x, y, z);
-  m.f_touched[child] = 1;
-  m.fnode[q] = (child_layer < P.max_layer) ? child : -1;   // VM:1152-1153
 }
 
 // tras_opt VM:1605-1638, pass 1: assign factor indices.
