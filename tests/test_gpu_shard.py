@@ -133,9 +133,12 @@ def _worker_hba(rank, world, port, out_dir, nk=25, n_pts=6000):
         nwin = (nk - 10) // 5 + 1
         payload = nwin * (3 + 45 * 50) + 3 * sum(len(c) for c in clouds)      # generous: every point kept in a submap cloud
         ok_coll = stats["calls"] <= 6 and stats["doubles"] <= world * payload
-        ok = (ok_coll and e1.shape == f1.shape and e2.shape == f2.shape and len(e1) > 0 and len(e2) > 0
-              and np.array_equal(e1[:, :2], f1[:, :2]) and np.array_equal(e2[:, :2], f2[:, :2])
-              and np.abs(e1 - f1).max() < 1e-6 * max(1.0, np.abs(f1).max()) and np.abs(e2 - f2).max() < 1e-6 * max(1.0, np.abs(f2).max()))
+        # edge rows: [id1, id2 | relative rotation (9) + translation (3) | 6 weights 1 / |H_kk|]; the GBA octree still sums with f64
+        # atomics, so the weights (reciprocals of Hessian diagonals) agree to the bar of tests/test_gpu_gba.py, the poses far tighter
+        def same(e, f):
+            return (e.shape == f.shape and len(e) > 0 and np.array_equal(e[:, :2], f[:, :2]) and np.abs(e[:, 2:14] - f[:, 2:14]).max() < 1e-6
+                    and np.allclose(e[:, 14:], f[:, 14:], rtol=1e-3, atol=0))
+        ok = ok_coll and same(e1, f1) and same(e2, f2)
         open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write(
             "edges %s %s vs %s %s | %g %g | collectives %s" % (e1.shape, e2.shape, f1.shape, f2.shape,
                                              np.abs(e1 - f1).max() if e1.shape == f1.shape else -1, np.abs(e2 - f2).max() if e2.shape == f2.shape else -1, stats))

@@ -575,6 +575,81 @@ __device__ __forceinline__ void slot_load(const FactorView &f, int v, int fi, in
   }
 }
 
+// Phase A of the Hessian pass for one (voxel, frame) slot: the slot's three rows g1, g2, h of G (6 columns each), the scales c_k,
+// and its contributions to the diagonal-block remainder E (Err 6 | Ert 9 | Ett 6), the gradient and the residual (VM:167-275).
+// R = the frame's pose [R | t]; `first` = this thread adds the voxel's coe * lambda_0 (one thread per voxel does).
+__device__ __forceinline__ void slot_terms(const SlotLoad &q, const double *R, bool first, double *g1, double *g2, double *hh, double &ck1, double &ck2, double &ck3,
+                                           double *Err, double *Ert, double *Ett, double *gj, double &rres) {
+if (q.valid) {
+  const double coe = q.coe, l0 = q.l0, NN = q.NN;
+  // reciprocals by v_rcp_f64 + two Newton steps (full f64 precision to an ulp) instead of five IEEE divisions per slot
+  const double inn = rcp_f64(NN);
+  const double c1 = 2.0 * rcp_f64(l0 - q.l1), c2 = 2.0 * rcp_f64(l0 - q.l2);      // VM:201
+  ck1 = coe * c1; ck2 = coe * c2; ck3 = coe * (-2.0 * inn * inn);
+  if (first) rres += coe * l0;                                    // VM:275
+  const double n = q.n;
+  if (n != 0.0) {
+    const double pxx = q.c[0], pxy = q.c[1], pxz = q.c[2], pyy = q.c[3], pyz = q.c[4], pzz = q.c[5];
+    const double vx = q.c[6], vy = q.c[7], vz = q.c[8];
+    const double u00 = q.U[0], u01 = q.U[1], u02 = q.U[2], u10 = q.U[3], u11 = q.U[4], u12 = q.U[5], u20 = q.U[6], u21 = q.U[7], u22 = q.U[8];
+    const double bx = q.vs0 * inn, by = q.vs1 * inn, bz = q.vs2 * inn;                                      // vBar (VM:190)
+    
+    const double k0 = u00, k1 = u10, k2 = u20;
+    const double a00 = R[0] * k0 + R[3] * k1 + R[6] * k2, a01 = R[1] * k0 + R[4] * k1 + R[7] * k2, a02 = R[2] * k0 + R[5] * k1 + R[8] * k2;
+    const double a10 = R[0] * u01 + R[3] * u11 + R[6] * u21, a11 = R[1] * u01 + R[4] * u11 + R[7] * u21, a12 = R[2] * u01 + R[5] * u11 + R[8] * u21;
+    const double a20 = R[0] * u02 + R[3] * u12 + R[6] * u22, a21 = R[1] * u02 + R[4] * u12 + R[7] * u22, a22 = R[2] * u02 + R[5] * u12 + R[8] * u22;
+    const double tx = R[9] - bx, ty = R[10] - by, tz = R[11] - bz;                                           // VM:224
+    const double s0 = k0 * tx + k1 * ty + k2 * tz, s1 = u01 * tx + u11 * ty + u21 * tz, s2 = u02 * tx + u12 * ty + u22 * tz;
+    const double pa00 = pxx * a00 + pxy * a01 + pxz * a02, pa01 = pxy * a00 + pyy * a01 + pyz * a02, pa02 = pxz * a00 + pyz * a01 + pzz * a02;
+    const double pa10 = pxx * a10 + pxy * a11 + pxz * a12, pa11 = pxy * a10 + pyy * a11 + pyz * a12, pa12 = pxz * a10 + pyz * a11 + pzz * a12;
+    const double pa20 = pxx * a20 + pxy * a21 + pxz * a22, pa21 = pxy * a20 + pyy * a21 + pyz * a22, pa22 = pxz * a20 + pyz * a21 + pzz * a22;
+    const double wx = pa00 + s0 * vx, wy = pa01 + s0 * vy, wz = pa02 + s0 * vz;                              // combo1 = hat(w) VM:228
+    const double c2x = R[0] * vx + R[1] * vy + R[2] * vz + n * tx;                                           // combo2 VM:229
+    const double c2y = R[3] * vx + R[4] * vy + R[5] * vz + n * ty;
+    const double c2z = R[6] * vx + R[7] * vy + R[8] * vz + n * tz;
+    const double qx = vy * a02 - vz * a01, qy = vz * a00 - vx * a02, qz = vx * a01 - vy * a00;              // viRiTuk VM:221
+    const double d0 = c2x * k0 + c2y * k1 + c2z * k2;
+    const double d1 = c2x * u01 + c2y * u11 + c2z * u21;
+    const double d2 = c2x * u02 + c2y * u12 + c2z * u22;
+    const double j0 = 2.0 * (wy * a02 - wz * a01) * inn, j1 = 2.0 * (wz * a00 - wx * a02) * inn, j2 = 2.0 * (wx * a01 - wy * a00) * inn;
+    const double j3 = 2.0 * d0 * k0 * inn, j4 = 2.0 * d0 * k1 * inn, j5 = 2.0 * d0 * k2 * inn;
+    gj[0] += coe * j0; gj[1] += coe * j1; gj[2] += coe * j2; gj[3] += coe * j3; gj[4] += coe * j4; gj[5] += coe * j5;   // VM:235-236
+    {
+      const double bx1 = pa10 + s1 * vx, by1 = pa11 + s1 * vy, bz1 = pa12 + s1 * vz;
+      g1[0] = (-(a01 * bz1 - a02 * by1) + (wy * a12 - wz * a11)) * inn;
+      g1[1] = (-(a02 * bx1 - a00 * bz1) + (wz * a10 - wx * a12)) * inn;
+      g1[2] = (-(a00 * by1 - a01 * bx1) + (wx * a11 - wy * a10)) * inn;
+      g1[3] = (k0 * d1 + d0 * u01) * inn; g1[4] = (k1 * d1 + d0 * u11) * inn; g1[5] = (k2 * d1 + d0 * u21) * inn;
+      const double bx2 = pa20 + s2 * vx, by2 = pa21 + s2 * vy, bz2 = pa22 + s2 * vz;
+      g2[0] = (-(a01 * bz2 - a02 * by2) + (wy * a22 - wz * a21)) * inn;
+      g2[1] = (-(a02 * bx2 - a00 * bz2) + (wz * a20 - wx * a22)) * inn;
+      g2[2] = (-(a00 * by2 - a01 * bx2) + (wx * a21 - wy * a20)) * inn;
+      g2[3] = (k0 * d2 + d0 * u02) * inn; g2[4] = (k1 * d2 + d0 * u12) * inn; g2[5] = (k2 * d2 + d0 * u22) * inn;
+    }
+    hh[0] = qx; hh[1] = qy; hh[2] = qz; hh[3] = n * k0; hh[4] = n * k1; hh[5] = n * k2;
+    const double wa = wx * a00 + wy * a01 + wz * a02;
+    const double t00 = a01 * pxz - a02 * pxy, t10 = a02 * pxx - a00 * pxz, t20 = a00 * pxy - a01 * pxx;
+    const double t01 = a01 * pyz - a02 * pyy, t11 = a02 * pxy - a00 * pyz, t21 = a00 * pyy - a01 * pxy;
+    const double t02 = a01 * pzz - a02 * pyz, t12 = a02 * pxz - a00 * pzz, t22 = a00 * pyz - a01 * pxz;
+    const double S00 = t01 * a02 - t02 * a01, S01 = -t00 * a02 + t02 * a00, S02 = t00 * a01 - t01 * a00;
+    const double S11 = -t10 * a02 + t12 * a00, S12 = t10 * a01 - t11 * a00;
+    const double S22 = t20 * a01 - t21 * a00;
+    const double e2 = 2.0 * inn * coe;
+    Err[0] += e2 * (a00 * wx - wa - S00);
+    Err[1] += e2 * (0.5 * (a00 * wy + wx * a01) - S01);
+    Err[2] += e2 * (0.5 * (a00 * wz + wx * a02) - S02);
+    Err[3] += e2 * (a01 * wy - wa - S11);
+    Err[4] += e2 * (0.5 * (a01 * wz + wy * a02) - S12);
+    Err[5] += e2 * (a02 * wz - wa - S22);
+    Ert[0] += e2 * qx * k0; Ert[1] += e2 * qx * k1; Ert[2] += e2 * qx * k2;
+    Ert[3] += e2 * qy * k0; Ert[4] += e2 * qy * k1; Ert[5] += e2 * qy * k2;
+    Ert[6] += e2 * qz * k0; Ert[7] += e2 * qz * k1; Ert[8] += e2 * qz * k2;
+    const double e3 = e2 * n;
+    Ett[0] += e3 * k0 * k0; Ett[1] += e3 * k0 * k1; Ett[2] += e3 * k0 * k2; Ett[3] += e3 * k1 * k1; Ett[4] += e3 * k1 * k2; Ett[5] += e3 * k2 * k2;
+  }
+}
+}
+
 // Device-resident LM loop, single rank: the accept / reject bookkeeping of the PREVIOUS iteration (VM:467-494) rides in the
 // prologue of the Hessian pass instead of being a kernel of its own.  Every workgroup re-derives the decision from r1 and the
 // residual pass' partials (same summation order everywhere, so the decision is bit-identical), runs only after an accepted
@@ -686,74 +761,7 @@ __global__ __launch_bounds__(HessCfg2<W>::NT) void k_hessian2(FactorView f, cons
       const SlotLoad q = nx;
       double g1[6] = {0, 0, 0, 0, 0, 0}, g2[6] = {0, 0, 0, 0, 0, 0}, hh[6] = {0, 0, 0, 0, 0, 0};
       double ck1 = 0.0, ck2 = 0.0, ck3 = 0.0;
-      if (q.valid) {
-        const double coe = q.coe, l0 = q.l0, NN = q.NN;
-        // reciprocals by v_rcp_f64 + two Newton steps (full f64 precision to an ulp) instead of five IEEE divisions per slot
-        const double inn = rcp_f64(NN);
-        const double c1 = 2.0 * rcp_f64(l0 - q.l1), c2 = 2.0 * rcp_f64(l0 - q.l2);      // VM:201
-        ck1 = coe * c1; ck2 = coe * c2; ck3 = coe * (-2.0 * inn * inn);
-        if (fi == 0) rres += coe * l0;                                    // VM:275
-        const double n = q.n;
-        if (n != 0.0) {
-          const double pxx = q.c[0], pxy = q.c[1], pxz = q.c[2], pyy = q.c[3], pyz = q.c[4], pzz = q.c[5];
-          const double vx = q.c[6], vy = q.c[7], vz = q.c[8];
-          const double u00 = q.U[0], u01 = q.U[1], u02 = q.U[2], u10 = q.U[3], u11 = q.U[4], u12 = q.U[5], u20 = q.U[6], u21 = q.U[7], u22 = q.U[8];
-          const double bx = q.vs0 * inn, by = q.vs1 * inn, bz = q.vs2 * inn;                                      // vBar (VM:190)
-          const double *R = sp + 12 * fi;
-          const double k0 = u00, k1 = u10, k2 = u20;
-          const double a00 = R[0] * k0 + R[3] * k1 + R[6] * k2, a01 = R[1] * k0 + R[4] * k1 + R[7] * k2, a02 = R[2] * k0 + R[5] * k1 + R[8] * k2;
-          const double a10 = R[0] * u01 + R[3] * u11 + R[6] * u21, a11 = R[1] * u01 + R[4] * u11 + R[7] * u21, a12 = R[2] * u01 + R[5] * u11 + R[8] * u21;
-          const double a20 = R[0] * u02 + R[3] * u12 + R[6] * u22, a21 = R[1] * u02 + R[4] * u12 + R[7] * u22, a22 = R[2] * u02 + R[5] * u12 + R[8] * u22;
-          const double tx = R[9] - bx, ty = R[10] - by, tz = R[11] - bz;                                           // VM:224
-          const double s0 = k0 * tx + k1 * ty + k2 * tz, s1 = u01 * tx + u11 * ty + u21 * tz, s2 = u02 * tx + u12 * ty + u22 * tz;
-          const double pa00 = pxx * a00 + pxy * a01 + pxz * a02, pa01 = pxy * a00 + pyy * a01 + pyz * a02, pa02 = pxz * a00 + pyz * a01 + pzz * a02;
-          const double pa10 = pxx * a10 + pxy * a11 + pxz * a12, pa11 = pxy * a10 + pyy * a11 + pyz * a12, pa12 = pxz * a10 + pyz * a11 + pzz * a12;
-          const double pa20 = pxx * a20 + pxy * a21 + pxz * a22, pa21 = pxy * a20 + pyy * a21 + pyz * a22, pa22 = pxz * a20 + pyz * a21 + pzz * a22;
-          const double wx = pa00 + s0 * vx, wy = pa01 + s0 * vy, wz = pa02 + s0 * vz;                              // combo1 = hat(w) VM:228
-          const double c2x = R[0] * vx + R[1] * vy + R[2] * vz + n * tx;                                           // combo2 VM:229
-          const double c2y = R[3] * vx + R[4] * vy + R[5] * vz + n * ty;
-          const double c2z = R[6] * vx + R[7] * vy + R[8] * vz + n * tz;
-          const double qx = vy * a02 - vz * a01, qy = vz * a00 - vx * a02, qz = vx * a01 - vy * a00;              // viRiTuk VM:221
-          const double d0 = c2x * k0 + c2y * k1 + c2z * k2;
-          const double d1 = c2x * u01 + c2y * u11 + c2z * u21;
-          const double d2 = c2x * u02 + c2y * u12 + c2z * u22;
-          const double j0 = 2.0 * (wy * a02 - wz * a01) * inn, j1 = 2.0 * (wz * a00 - wx * a02) * inn, j2 = 2.0 * (wx * a01 - wy * a00) * inn;
-          const double j3 = 2.0 * d0 * k0 * inn, j4 = 2.0 * d0 * k1 * inn, j5 = 2.0 * d0 * k2 * inn;
-          gj[0] += coe * j0; gj[1] += coe * j1; gj[2] += coe * j2; gj[3] += coe * j3; gj[4] += coe * j4; gj[5] += coe * j5;   // VM:235-236
-          {
-            const double bx1 = pa10 + s1 * vx, by1 = pa11 + s1 * vy, bz1 = pa12 + s1 * vz;
-            g1[0] = (-(a01 * bz1 - a02 * by1) + (wy * a12 - wz * a11)) * inn;
-            g1[1] = (-(a02 * bx1 - a00 * bz1) + (wz * a10 - wx * a12)) * inn;
-            g1[2] = (-(a00 * by1 - a01 * bx1) + (wx * a11 - wy * a10)) * inn;
-            g1[3] = (k0 * d1 + d0 * u01) * inn; g1[4] = (k1 * d1 + d0 * u11) * inn; g1[5] = (k2 * d1 + d0 * u21) * inn;
-            const double bx2 = pa20 + s2 * vx, by2 = pa21 + s2 * vy, bz2 = pa22 + s2 * vz;
-            g2[0] = (-(a01 * bz2 - a02 * by2) + (wy * a22 - wz * a21)) * inn;
-            g2[1] = (-(a02 * bx2 - a00 * bz2) + (wz * a20 - wx * a22)) * inn;
-            g2[2] = (-(a00 * by2 - a01 * bx2) + (wx * a21 - wy * a20)) * inn;
-            g2[3] = (k0 * d2 + d0 * u02) * inn; g2[4] = (k1 * d2 + d0 * u12) * inn; g2[5] = (k2 * d2 + d0 * u22) * inn;
-          }
-          hh[0] = qx; hh[1] = qy; hh[2] = qz; hh[3] = n * k0; hh[4] = n * k1; hh[5] = n * k2;
-          const double wa = wx * a00 + wy * a01 + wz * a02;
-          const double t00 = a01 * pxz - a02 * pxy, t10 = a02 * pxx - a00 * pxz, t20 = a00 * pxy - a01 * pxx;
-          const double t01 = a01 * pyz - a02 * pyy, t11 = a02 * pxy - a00 * pyz, t21 = a00 * pyy - a01 * pxy;
-          const double t02 = a01 * pzz - a02 * pyz, t12 = a02 * pxz - a00 * pzz, t22 = a00 * pyz - a01 * pxz;
-          const double S00 = t01 * a02 - t02 * a01, S01 = -t00 * a02 + t02 * a00, S02 = t00 * a01 - t01 * a00;
-          const double S11 = -t10 * a02 + t12 * a00, S12 = t10 * a01 - t11 * a00;
-          const double S22 = t20 * a01 - t21 * a00;
-          const double e2 = 2.0 * inn * coe;
-          Err[0] += e2 * (a00 * wx - wa - S00);
-          Err[1] += e2 * (0.5 * (a00 * wy + wx * a01) - S01);
-          Err[2] += e2 * (0.5 * (a00 * wz + wx * a02) - S02);
-          Err[3] += e2 * (a01 * wy - wa - S11);
-          Err[4] += e2 * (0.5 * (a01 * wz + wy * a02) - S12);
-          Err[5] += e2 * (a02 * wz - wa - S22);
-          Ert[0] += e2 * qx * k0; Ert[1] += e2 * qx * k1; Ert[2] += e2 * qx * k2;
-          Ert[3] += e2 * qy * k0; Ert[4] += e2 * qy * k1; Ert[5] += e2 * qy * k2;
-          Ert[6] += e2 * qz * k0; Ert[7] += e2 * qz * k1; Ert[8] += e2 * qz * k2;
-          const double e3 = e2 * n;
-          Ett[0] += e3 * k0 * k0; Ett[1] += e3 * k0 * k1; Ett[2] += e3 * k0 * k2; Ett[3] += e3 * k1 * k1; Ett[4] += e3 * k1 * k2; Ett[5] += e3 * k2 * k2;
-        }
-      }
+      slot_terms(q, sp + 12 * fi, fi == 0, g1, g2, hh, ck1, ck2, ck3, Err, Ert, Ett, gj, rres);
       double *g = G + (size_t)(3 * vl) * C::GS + 6 * fi;
 #pragma unroll
       for (int d = 0; d < 6; d++) { g[d] = g1[d]; g[C::GS + d] = g2[d]; g[2 * C::GS + d] = hh[d]; }

@@ -90,7 +90,12 @@ struct MapView {
   int *pnode;   // [W][max_pts]
   int *phash;   // [max_pts] temp
   int *newslots;  // [max_pts] temp
-  int *perm;    // [W][max_pts] point indices of a slot grouped by insertion leaf, scan order inside a group (stable sort)
+  int *perm;    // [W][max_pts] point indices of a slot grouped by insertion leaf, scan order inside a group
+  // the slot's points IN THAT ORDER (what sw->points[mord] of the leaves hold in the reference): the passes that walk a leaf's points again
+  // (subdivide, the move of the oldest frame to point_fix) stream them instead of chasing perm -> point
+  double *sx;   // [3][W][max_pts]
+  double *svar; // [9][W][max_pts]
+  int *pleaf;   // [W][max_pts] the leaf that holds the point NOW (-1: none / released)
   unsigned int *skey_a, *skey_b;   // [max_pts] sort keys (leaf id) in / out
   int *sval_a;  // [max_pts] sort values in (the point index)
   int *wl;      // [max_pts] leaves that received points of the scan being inserted
@@ -203,6 +208,8 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
   if (!world_given) {   // the slot's previous occupant is gone: its insertion segments are cleared here (k_ins_scan writes the new ones)
     int *sa = m.nseg_a + (size_t)slot * m.cap, *sb = m.nseg_b + (size_t)slot * m.cap;
     for (int i = p; i < m.cap; i += gridDim.x * blockDim.x) { sa[i] = 0; sb[i] = 0; }
+    int *pl = m.pleaf + (size_t)slot * m.max_pts;
+    for (int i = p; i < m.max_pts; i += gridDim.x * blockDim.x) pl[i] = -1;
   }
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
   int hslot = -1, root = -1;
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256) void k_ins_scatter(MapView m, int slot, int n)
 // one chunk of <= 64 points of a leaf in scan order: lane j prepares the terms of point j, lane k adds term k of the points in order.
 // The terms are staged in two rounds of <= 32 (the LDS image of all 63 would hold a CU to 4 waves).
 template <bool HAS_VAR>
-__device__ __forceinline__ void ord_chunk(const MapView &m, const MapParams &P, int slot, int p, int cnt, int lane, double *T, double &acc) {
+__device__ __forceinline__ void ord_chunk(const MapView &m, const MapParams &P, int slot, int p, int pos, int leaf, int cnt, int lane, double *T, double &acc) {
   using C = OrdCfg<HAS_VAR>;
   constexpr int NR = HAS_VAR ? 2 : 1, RT = HAS_VAR ? 32 : 18, TS = RT | 1;
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
@@ -401,6 +408,13 @@ __device__ __forceinline__ void ord_chunk(const MapView &m, const MapParams &P, 
     double x, y, z;
     world_point(m.poses, bx, by, bz, x, y, z);
     ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
+    // the point joins the leaf's ordered storage
+    m.sx[(0 * W + slot) * mpz + pos] = bx; m.sx[(1 * W + slot) * mpz + pos] = by; m.sx[(2 * W + slot) * mpz + pos] = bz;
+    if (HAS_VAR) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) m.svar[((size_t)k * W + slot) * mpz + pos] = var[k];
+    }
+    m.pleaf[(size_t)slot * mpz + pos] = leaf;
   }
 #pragma unroll
   for (int r = 0; r < NR; r++) {
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
     const int p = lane < cnt ? sp[lane] : 0;
     if (lane < cnt) perm[start + lane] = p;              // the segment in scan order (recut / margi read it again)
-    ord_chunk<HAS_VAR>(m, P, slot, p, cnt, lane, T, acc);
+    ord_chunk<HAS_VAR>(m, P, slot, p, start + lane, leaf, cnt, lane, T, acc);
     if (lane < C::NT) tgt[leaf] = acc;
     if (lane == 63) {                                    // N of both clusters: integers, exact in f64
       m.nlc[((size_t)9 * W + slot) * cp + leaf] += (double)cnt;
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(256) void k_ins_accum_big(MapView m, MapParams P, i
       for (int c0 = 0; c0 < cnt; c0 += 64) {
         const int cc = cnt - c0 < 64 ? cnt - c0 : 64;
         const int p = lane < cc ? perm[start + c0 + lane] : 0;
-        ord_chunk<HAS_VAR>(m, P, slot, p, cc, lane, T, acc);
+        ord_chunk<HAS_VAR>(m, P, slot, p, start + c0 + lane, leaf, cc, lane, T, acc);
       }
       if (lane < C::NT) tgt[leaf] = acc;
       if (lane == 63) {
@@ -792,19 +806,19 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
       if (tpos < total) {
         while (tpos >= foff[f + 1]) f++;
         const int slot = P.mp[f];
-        const int p = m.perm[(size_t)slot * mpz + fs[f] + (tpos - foff[f])];
-        if (m.pnode[(size_t)slot * mpz + p] == X) {
-          const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+        const size_t p = (size_t)(fs[f] + (tpos - foff[f]));      // position in the slot's ordered storage: no indirection
+        if (m.pleaf[(size_t)slot * mpz + p] == X) {
+          const double bx = m.sx[(0 * W + slot) * mpz + p], by = m.sx[(1 * W + slot) * mpz + p], bz = m.sx[(2 * W + slot) * mpz + p];
           double var[9];
           if (HAS_VAR) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+            for (int k = 0; k < 9; k++) var[k] = m.svar[((size_t)k * W + slot) * mpz + p];
           }
           double x, y, z;
           world_point(m.poses + 12 * f, bx, by, bz, x, y, z);
           child = octant_of(m, X, x, y, z);
           ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
-          m.pnode[(size_t)slot * mpz + p] = base + child;
+          m.pleaf[(size_t)slot * mpz + p] = base + child;
         }
       }
       fj[lane] = f;
@@ -1058,14 +1072,17 @@ __device__ __forceinline__ void plane_update_dev(const MapView &m, int id, const
 }
 
 // One thread per leaf: OctoTree::margi leaf branch VM:1468-1584 with mgsize = 1.
-__device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id);
+__device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id, const int *smp);
 __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, FactorView f, int nfac, int win_count, int epoch) {
   __shared__ int wtake[4], wcnt[4], bases[3];
+  __shared__ int smp[VBA_MAX_WIN];                       // the ring map: indexed per lane below (a kernel argument cannot be)
+  if (threadIdx.x < VBA_MAX_WIN) smp[threadIdx.x] = P.mp[threadIdx.x];
+  __syncthreads();
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
   // > 0: the leaf's oldest frame (that many points) joins point_fix.  The pool range, the block id and the place on the work list
   // of k_margi_take are reserved here with ONE returning atomic each per workgroup (per leaf they serialised: ~10 ns each in L2)
-  const int count = id < nn ? margi_leaf_body(m, P, f, nfac, win_count, epoch, id) : 0;
+  const int count = id < nn ? margi_leaf_body(m, P, f, nfac, win_count, epoch, id, smp) : 0;
   const bool take = count > 0;
   const unsigned long long mask = __ballot(take);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1096,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, Fact
     }
   }
 }
-__device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id) {
+__device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams &P, const FactorView &f, int nfac, int win_count, int epoch, int id, const int *smp) {
   int take = 0;
   if (m.nstate[id] != 0 || m.nlayer[id] < 0) return 0;        // internal node, or freed storage
   if (slide_count(m, P) < P.thread_num) return 0;              // VS:1616-1617
@@ -1120,13 +1137,22 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
     if (lc[9] != 0.0) cluster_transform_dev(lc, m.poses, pw0);
   } else {                                                  // VM:1510-1529
     for (int k = 0; k < 10; k++) add[k] = fix[k];
+    // which frames hold points: the N column of every slot in ONE memory trip (unrolled loads), then a rolled loop over the occupied
+    // frames only (unrolled over 16 frames the exact-order transform was 2400 f64 operations of straight-line code per thread)
+    unsigned int occm = 0;
+    {
+      double nn[VBA_MAX_WIN_DEV];
+#pragma unroll
+      for (int i = 0; i < VBA_MAX_WIN_DEV; i++) nn[i] = (i < win_count) ? m.nlc[((size_t)9 * W + P.mp[i < win_count ? i : 0]) * cp + id] : 0.0;
+#pragma unroll
+      for (int i = 0; i < VBA_MAX_WIN_DEV; i++) occm |= (nn[i] != 0.0) ? (1u << i) : 0u;
+    }
 #pragma unroll 1
-    for (int i = 0; i < win_count; i++) {                    // (rolled: unrolled over 16 frames the exact-order transform cost 255 registers + scratch)
-      const int slot = P.mp[i];
-      const double ni = m.nlc[((size_t)9 * W + slot) * cp + id];
-      if (ni == 0.0) continue;
-      for (int k = 0; k < 9; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
-      lc[9] = ni;
+    while (occm) {
+      const int i = __ffs((int)occm) - 1;
+      occm &= occm - 1;
+      const int slot = smp[i];
+      for (int k = 0; k < 10; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
       double t[10];
       cluster_transform_dev(lc, m.poses + 12 * i, t);
       for (int k = 0; k < 10; k++) add[k] += t[k];
@@ -1169,8 +1195,7 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
   const int ntake = m.cnt[CNT_TAKE];
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
   const int slot = P.mp[0];
-  const int *perm = m.perm + (size_t)slot * mpz;
-  const int *pnode = m.pnode + (size_t)slot * mpz;
+  const int *pleaf = m.pleaf + (size_t)slot * mpz;
   for (int s = blockIdx.x; s < ntake; s += gridDim.x) {
     const int X = m.nsl[s], qb = m.wl[s], count = m.wlb[s];      // pool range and chain block were reserved by k_margi_leaf
     if (count == 0) continue;
@@ -1181,18 +1206,18 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
     int off = 0;
     for (int c0 = start; c0 < end; c0 += 64) {
       const int i = c0 + lane;
-      const int p = perm[i < end ? i : start];
-      const bool mine = i < end && pnode[p] == X;
+      const size_t p = (size_t)(i < end ? i : start);          // position in the slot's ordered storage
+      const bool mine = i < end && pleaf[p] == X;
       const unsigned long long mk = __ballot(mine);
       if (mine) {
         const int o = off + __popcll(mk & ((1ull << lane) - 1ull));
         if (o < count) {
           const int q = qb + o;
-          const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+          const double bx = m.sx[(0 * W + slot) * mpz + p], by = m.sx[(1 * W + slot) * mpz + p], bz = m.sx[(2 * W + slot) * mpz + p];
           double wx, wy, wz;
           world_point(m.poses, bx, by, bz, wx, wy, wz);                    // pv.pnt = x_buf[0].R * pv.pnt + x_buf[0].p  VM:1551
           m.fx[q] = wx; m.fx[cf + q] = wy; m.fx[2 * cf + q] = wz;
-          for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.pvar[((size_t)k * W + slot) * mpz + p] : 0.0;
+          for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.svar[((size_t)k * W + slot) * mpz + p] : 0.0;
           m.fnode[q] = X;
         }
       }
@@ -1206,7 +1231,7 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
 // slot mp[0] is emptied (VM:1569-1574: points[mp[0]].clear())
 __global__ __launch_bounds__(1024) void k_margi_points(MapView m, MapParams P) {
   const int p = blockIdx.x * 1024 + threadIdx.x;
-  if (p < m.max_pts) m.pnode[(size_t)P.mp[0] * m.max_pts + p] = -1;
+  if (p < m.max_pts) m.pleaf[(size_t)P.mp[0] * m.max_pts + p] = -1;
 }
 __global__ void k_margi_fixclear(MapView m, int epoch) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1251,7 +1276,7 @@ __global__ void k_margi_clear_points(MapView m, MapParams P, int epoch) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = blockIdx.y;
   if (p >= m.max_pts) return;
-  int *pn = m.pnode + (size_t)slot * m.max_pts + p;
+  int *pn = m.pleaf + (size_t)slot * m.max_pts + p;
   const int node = *pn;
   if (node >= 0 && m.ndead[m.nroot[node]] == epoch) *pn = -1;
 }
@@ -1650,7 +1675,7 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
 }
 inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
   return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1},
-          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}, {(void **)&v.wlb, 4, 1}, {(void **)&v.wl4, 16, 1}};
+          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.sx, 8, (size_t)3 * W}, {(void **)&v.svar, 8, (size_t)9 * W}, {(void **)&v.pleaf, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}, {(void **)&v.wlb, 4, 1}, {(void **)&v.wl4, 16, 1}};
 }
 inline std::vector<DevArr> fix_arrays(MapView &v) {
   return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}, {(void **)&v.fb_base, 4, 1}, {(void **)&v.fb_len, 4, 1}, {(void **)&v.fb_next, 4, 1}};
@@ -1729,10 +1754,12 @@ inline int map_ensure(MapStore &s, hipStream_t st, size_t need_nodes, size_t nee
     while (nc < need_pts) nc *= 2;
     int r = grow_arrays(scan_arrays(s.v, W), (size_t)s.v.max_pts, nc, (size_t)s.v.max_pts, st, err);
     if (r) return r;
-    if (s.v.max_pts == 0) MAPCHK(hipMemsetAsync(s.v.pnode, 0xFF, (size_t)W * nc * 4, st));
+    if (s.v.max_pts == 0) { MAPCHK(hipMemsetAsync(s.v.pnode, 0xFF, (size_t)W * nc * 4, st)); MAPCHK(hipMemsetAsync(s.v.pleaf, 0xFF, (size_t)W * nc * 4, st)); }
     else {  // new tail of every slot must read "no node"
-      for (int sl = 0; sl < W; sl++)
+      for (int sl = 0; sl < W; sl++) {
         MAPCHK(hipMemsetAsync(s.v.pnode + (size_t)sl * nc + s.v.max_pts, 0xFF, (nc - s.v.max_pts) * 4, st));
+        MAPCHK(hipMemsetAsync(s.v.pleaf + (size_t)sl * nc + s.v.max_pts, 0xFF, (nc - s.v.max_pts) * 4, st));
+      }
     }
     s.v.max_pts = (int)nc;
   }
@@ -2069,6 +2096,7 @@ inline int map_reset(MapStore &s, hipStream_t st, std::string &err) {
   hipStreamSynchronize(st);
   for (auto &a : node_arrays(s.v, W)) MAPCHK(hipMemsetAsync(*a.slot, 0, a.elem * a.rows * (size_t)s.v.cap, st));
   if (s.v.pnode) MAPCHK(hipMemsetAsync(s.v.pnode, 0xFF, (size_t)W * s.v.max_pts * 4, st));
+  if (s.v.pleaf) MAPCHK(hipMemsetAsync(s.v.pleaf, 0xFF, (size_t)W * s.v.max_pts * 4, st));
   if (s.v.fnode) MAPCHK(hipMemsetAsync(s.v.fnode, 0xFF, (size_t)s.v.cap_fix * 4, st));
   hipLaunchKernelGGL(k_fill_u64, dim3(1024), dim3(256), 0, st, s.v.hkeys, KEY_EMPTY, (size_t)s.hcap);
   MAPCHK(hipMemsetAsync(s.v.hvals, 0xFF, (size_t)s.hcap * 4, st));
