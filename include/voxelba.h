@@ -79,6 +79,7 @@ typedef struct vba_options {
   int force_collective;             /* != 0: take the exchange step of the sharded LM flow with ONE rank too (rehearsals) */
   int hessian_workgroups;           /* persistent workgroups of the Hessian pass, 2..256 (default 256 = one per CU) */
   int residual_vpl_from;            /* residual pass: stores with more voxels use the voxel-per-lane kernel (default 45000) */
+  int hessian_compact_tiles;        /* != 0: Hessian pass on occupancy-compact tiles (k_hessian3, W <= 10) instead of dense fixed-size ones; measured slower at the bench size */
 } vba_options;
 
 void vba_default_options(vba_options *opt); /* values of config/avia.yaml:26-47 */

@@ -329,7 +329,8 @@ def test_long_session_prune_reuses_hash_slots_and_nodes(capi, oracle, synth):
 
 def test_extracted_factors_are_in_occupancy_mask_order(oracle):
     """tras_opt on the device stores the factors in occupancy-mask order (whole memory lines per frame instead of
-    scattered slots).  The masks must be non-decreasing, agree with the oracle's factor set as a multiset, and opt_state must follow."""
+    scattered slots; the Hessian pass tiles runs of voxels that see the same frames): popcount descending, then the mask.  The store
+    must be in that order, agree with the oracle's factor set as a multiset, and opt_state must follow."""
     import voxel_slam_amd  # noqa: F401
     from voxel_slam_amd import capi, synth
     wl = synth.CONFIGS["avia100k_w10"]
@@ -344,7 +345,10 @@ def test_extracted_factors_are_in_occupancy_mask_order(oracle):
     ctx.recut(W, poses, multi=False); om.recut(W, poses, of, multi=False)
     m = ctx.factor_occupancy_masks()
     assert len(m) == of.size() > 1000
-    assert (np.diff((m & 1023).astype(np.int64)) >= 0).all()
+    mm = (m & 1023).astype(np.int64)
+    pcnt = np.array([bin(int(x)).count("1") for x in mm])
+    key = -pcnt * 4096 + mm                                   # popcount descending, mask ascending
+    assert (np.diff(key) >= 0).all()
     cl, _, _ = of.read_inputs()
     mo = ((cl[:, :, 9] != 0) * (1 << np.arange(W))[None, :]).sum(1).astype(np.uint32)
     assert np.array_equal(np.sort(m), np.sort(mo))

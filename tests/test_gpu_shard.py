@@ -60,11 +60,13 @@ def _worker(rank, world, port, out_dir, name="room20k_w4"):
         # (the two ranks' partial Hessians are added in a different order than the single rank's workgroup partials: 18k voxels
         #  at full size, with cancellation between them, leave ~1e-8 of the largest entry; the LI-BA full-size test uses the same bar)
         htol = 1e-7 if name == "hesai200k_w10" else 1e-8
+        def same_trace(a, b):      # accepted rows tightly; a rejected trial step comes out of an ill-conditioned solve (tests/test_gpu_factor.py)
+            return a.shape == b.shape and all(np.allclose(ra, rb, rtol=1e-7 if rb[1] < rb[0] else 1e-4, atol=1e-12) for ra, rb in zip(a, b))
         ok = (int(cnt.item()) == nv_f and np.abs(sharded["poses"] - full["poses"]).max() < 1e-8
-              and np.allclose(sharded["trace"], full["trace"], rtol=1e-7, atol=1e-12)
+              and same_trace(sharded["trace"], full["trace"])
               and np.abs(sharded["hess"] - full["hess"]).max() < htol * np.abs(full["hess"]).max()
               and np.abs(li_s["states"] - li_f["states"]).max() < 1e-8
-              and np.allclose(li_s["trace"], li_f["trace"], rtol=1e-7, atol=1e-12)
+              and same_trace(li_s["trace"], li_f["trace"])
               and np.abs(li_s["hess"] - li_f["hess"]).max() < htol * np.abs(li_f["hess"]).max())
         open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write(
             "voxels %d %d | lidar poses %g | LI states %g FULLROW0 %s trace %s vs %s hess %g" % (

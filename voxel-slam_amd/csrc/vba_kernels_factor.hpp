@@ -19,9 +19,27 @@ struct FactorView {
   double *pcr;     // [10][vs]      pcr_adds
   unsigned int *occ;   // [vs]      bit i set <=> slot (voxel, frame i) holds points (cl N != 0): what the residual pass tests instead of
                        //           reading the N of all W slots (4 B per voxel instead of 8 W); kept current by k_factor_mask
+  int *tiles;      // Hessian-pass tile table (k_factor_tiles): [0] = number of tiles, then (first voxel, voxels, union mask, 0) from [4]
   int vs;          // voxel stride (capacity)
   int W;
 };
+
+// Rank of an occupancy mask of `nb` frames in the store order: popcount DESCENDING, masks of one popcount in ascending numeric order
+// (colexicographic rank).  Equal masks share a bucket, so the counting sort of the extraction keeps them adjacent.
+__host__ __device__ inline int mask_bucket(unsigned int m, int nb) {
+  constexpr int C[11][11] = {{1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0}, {1, 3, 3, 1, 0, 0, 0, 0, 0, 0, 0},
+                             {1, 4, 6, 4, 1, 0, 0, 0, 0, 0, 0}, {1, 5, 10, 10, 5, 1, 0, 0, 0, 0, 0}, {1, 6, 15, 20, 15, 6, 1, 0, 0, 0, 0},
+                             {1, 7, 21, 35, 35, 21, 7, 1, 0, 0, 0}, {1, 8, 28, 56, 70, 56, 28, 8, 1, 0, 0}, {1, 9, 36, 84, 126, 126, 84, 36, 9, 1, 0},
+                             {1, 10, 45, 120, 210, 252, 210, 120, 45, 10, 1}};
+  int p = 0;
+  for (int b = 0; b < nb; b++) p += (m >> b) & 1u;
+  int off = 0;
+  for (int q = nb; q > p; q--) off += C[nb][q];
+  int r = 0, k = 0;
+  for (int b = 0; b < nb; b++)
+    if ((m >> b) & 1u) { k++; r += C[b][k]; }
+  return off + r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Symmetric 3x3 eigen-decomposition, ascending eigenvalues, orthonormal eigenvectors in columns.

@@ -935,6 +935,7 @@ __global__ __launch_bounds__(256) void k_extract_key(MapView m, MapParams P, int
     const size_t cp = (size_t)m.cap, W = (size_t)P.W;
     unsigned int key = 0;
     for (int i = 0; i < P.W && i < 10; i++) key |= (m.nlc[((size_t)9 * W + P.mp[i]) * cp + id] != 0.0) ? (1u << i) : 0u;
+    key = (unsigned int)mask_bucket(key, P.W < 10 ? P.W : 10);   // order of the store: popcount DESCENDING, then the mask (heavy tiles of the Hessian pass first)
     m.nfkey[a] = key;
     m.nfl2[a] = id;
     atomicAdd(&lh[key], 1);

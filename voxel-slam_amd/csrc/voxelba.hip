@@ -5,6 +5,7 @@
 
 #define VBA_MAX_WIN_DEV VBA_MAX_WIN
 #include "vba_kernels_factor.hpp"
+#include "vba_kernels_h3.hpp"
 #include "vba_kernels_map.hpp"
 #include "vba_kernels_lm.hpp"
 #include "vba_kernels_li.hpp"
@@ -121,6 +122,7 @@ struct vba_ctx {
   bool force_collective = false;  // vba_options::force_collective (rehearsal: run the exchange step with one rank)
   int max_blocks_hess = 256;      // vba_options::hessian_workgroups
   int residual_vpl_from = 45000;  // vba_options::residual_vpl_from
+  bool use_h3 = false;            // vba_options::hessian_compact_tiles != 0
   ncclComm_t comm = nullptr;      // RCCL communicator: the exchange step is issued by the library on the context's stream
   bool own_comm = false;
   bool collective_off = false;    // replica phases (bottom-layer HBA windows) run their LM loops without the exchange step
@@ -231,13 +233,18 @@ int factor_reserve(vba_ctx *c, int need) {
                                  (size_t)c->nvox * sizeof(double), rows[k], hipMemcpyDeviceToDevice, c->stream));
   }
   unsigned int *oocc = c->fv.occ;
+  int *otiles = c->fv.tiles;
+  HIPCHK(c, hipMalloc((void **)&n.tiles, ((size_t)4 * newcap + 16) * sizeof(int)));
+  HIPCHK(c, hipMemsetAsync(n.tiles, 0, ((size_t)4 * newcap + 16) * sizeof(int), c->stream));
   HIPCHK(c, hipMalloc((void **)&n.occ, (size_t)newcap * sizeof(unsigned int)));
   HIPCHK(c, hipMemsetAsync(n.occ, 0, (size_t)newcap * sizeof(unsigned int), c->stream));
   if (c->nvox > 0 && oocc) HIPCHK(c, hipMemcpyAsync(n.occ, oocc, (size_t)c->nvox * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int k = 0; k < 6; k++) if (op[k]) hipFree(op[k]);
   if (oocc) hipFree(oocc);
+  if (otiles) hipFree(otiles);
   c->fv = n;
+  if (c->nvox > 0) hipLaunchKernelGGL(k_factor_tiles, dim3(1), dim3(1024), 0, c->stream, c->fv, c->nvox);   // (the table lives in the new allocation)
   c->cap = newcap;
   return VBA_OK;
 }
@@ -245,6 +252,8 @@ int factor_reserve(vba_ctx *c, int need) {
 // the occupancy masks of voxels [base, base + n) follow every write of the cluster rows
 void factor_update_mask(vba_ctx *c, int base, int n) {
   if (n > 0) hipLaunchKernelGGL(k_factor_mask, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fv, base, n);
+  // the Hessian pass' tile table of the whole store [0, base + n) (vba_kernels_h3.hpp)
+  if (base + n > 0) hipLaunchKernelGGL(k_factor_tiles, dim3(1), dim3(1024), 0, c->stream, c->fv, base + n);
 }
 
 int upload_poses(vba_ctx *c, const double *poses) {
@@ -301,8 +310,55 @@ int launch_hessian2_t(vba_ctx *c, const double *poses_dev, const int *gate, int 
   return VBA_OK;
 }
 
+template <int W>
+int launch_hessian3_t(vba_ctx *c, const double *poses_dev, const int *gate, int *nblocks_out, LmDev *lm, const double *k4p, int k4nb, const LiJob &li, size_t li_lds) {
+  using C = HessCfg3<W>;
+  const int nb = li.dev ? c->max_blocks_hess - 1 : c->max_blocks_hess;      // (the IMU workgroup of LI-BA takes a CU of its own)
+  static bool attr_set[kMaxDevices] = {false};
+  if (!attr_set[c->device % kMaxDevices]) {
+    const size_t li_max = 150 * 1024;
+    hipFuncSetAttribute((const void *)k_hessian3<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES > li_max ? C::LDS_BYTES : li_max));
+    attr_set[c->device % kMaxDevices] = true;
+  }
+  const size_t lds = (li.dev && li_lds > C::LDS_BYTES) ? li_lds : C::LDS_BYTES;
+  long long *stamps = nullptr;
+  static const bool want_stamps = diag_env("VBA_K3_STAMPS") != nullptr;     // -DVBA_DIAG builds only
+  if (want_stamps) {
+    static long long *d_st = nullptr;
+    if (!d_st) hipMalloc((void **)&d_st, (size_t)kMaxBlocksHess * 16 * 8);
+    hipMemsetAsync(d_st, 0, (size_t)kMaxBlocksHess * 16 * 8, c->stream);
+    stamps = d_st;
+  }
+  hipLaunchKernelGGL(k_hessian3<W>, dim3(nb + (li.dev ? 1 : 0)), dim3(C::NT), lds, c->stream, c->fv, poses_dev, c->nvox, c->d_partial, gate, lm, k4p, k4nb, nb, li, stamps);
+  if (want_stamps) {
+    std::vector<long long> h((size_t)nb * 16);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    long long t0 = h[0];
+    for (int b = 0; b < nb; b++) if (h[(size_t)b * 16] && h[(size_t)b * 16] < t0) t0 = h[(size_t)b * 16];
+    for (int b : {0, 1, nb / 2, nb - 1}) {
+      fprintf(stderr, "[k3 stamps] wg %d:", b);
+      for (int i = 0; i < 16; i++) fprintf(stderr, " %lld", h[(size_t)b * 16 + i] ? h[(size_t)b * 16 + i] - t0 : -1);
+      fprintf(stderr, "\n");
+    }
+    long long tmax = 0;
+    for (int b = 0; b < nb; b++) if (h[(size_t)b * 16 + 15] - t0 > tmax) tmax = h[(size_t)b * 16 + 15] - t0;
+    fprintf(stderr, "[k3 stamps] last workgroup ends at %lld ticks (100 MHz wall clock: 1 tick = 10 ns); per workgroup: start, prologue, then per tile [A, B, combine, E]\n", tmax);
+  }
+  *nblocks_out = nb;
+  return VBA_OK;
+}
+
 int launch_hessian(vba_ctx *c, const double *pd, const int *gate, int head, int end, int *nb, LmDev *lm = nullptr, const double *k4p = nullptr, int k4nb = 0,
                    const LiJob &li = LiJob{}, size_t li_lds = 0) {
+  // whole store, W <= 10: the occupancy-compact pass (vba_kernels_h3.hpp); sub-ranges and wider windows: the dense-tile pass
+  if (head == 0 && end == c->nvox && c->opt.win_size <= 10 && c->use_h3) {
+    switch (c->opt.win_size) {
+#define VBA_H3_CASE(WW) case WW: return launch_hessian3_t<WW>(c, pd, gate, nb, lm, k4p, k4nb, li, li_lds);
+      VBA_H3_CASE(2) VBA_H3_CASE(3) VBA_H3_CASE(4) VBA_H3_CASE(5) VBA_H3_CASE(6) VBA_H3_CASE(7) VBA_H3_CASE(8) VBA_H3_CASE(9) VBA_H3_CASE(10)
+#undef VBA_H3_CASE
+    }
+  }
   switch (c->opt.win_size) {
 #define VBA_H_CASE(WW) case WW: return launch_hessian2_t<WW>(c, pd, gate, head, end, nb, lm, k4p, k4nb, li, li_lds);
     VBA_H_CASE(2) VBA_H_CASE(3) VBA_H_CASE(4) VBA_H_CASE(5) VBA_H_CASE(6) VBA_H_CASE(7) VBA_H_CASE(8) VBA_H_CASE(9) VBA_H_CASE(10)
@@ -543,6 +599,7 @@ int vba_create(const vba_options *opt, vba_ctx **out) {
   c->max_blocks_hess = opt->hessian_workgroups > 0 ? std::min(opt->hessian_workgroups, kMaxBlocksHess) : kMaxBlocksHess;
   if (c->max_blocks_hess < 2) c->max_blocks_hess = 2;      // (LI-BA gives one workgroup's CU to the IMU factors)
   c->residual_vpl_from = opt->residual_vpl_from > 0 ? opt->residual_vpl_from : 45000;
+  c->use_h3 = opt->hessian_compact_tiles != 0;
   if (opt->stream) { c->stream = (hipStream_t)opt->stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VBA_ERR_HIP; }
@@ -584,6 +641,7 @@ void vba_destroy(vba_ctx *c) {
   double *p[] = {c->fv.cl, c->fv.fix, c->fv.coe, c->fv.eigval, c->fv.eigvec, c->fv.pcr, c->d_poses, c->d_partial, c->d_out, c->d_full, c->d_scal};
   for (double *q : p) if (q) hipFree(q);
   if (c->fv.occ) hipFree(c->fv.occ);
+  if (c->fv.tiles) hipFree(c->fv.tiles);
   if (c->d_stage) hipFree(c->d_stage);
   if (c->h_pin) hipHostFree(c->h_pin);
   if (c->d_lm) hipFree(c->d_lm);
