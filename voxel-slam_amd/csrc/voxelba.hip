@@ -244,7 +244,7 @@ int factor_reserve(vba_ctx *c, int need) {
   if (oocc) hipFree(oocc);
   if (otiles) hipFree(otiles);
   c->fv = n;
-  if (c->nvox > 0) hipLaunchKernelGGL(k_factor_tiles, dim3(1), dim3(1024), 0, c->stream, c->fv, c->nvox);   // (the table lives in the new allocation)
+  if (c->nvox > 0 && c->use_h3) hipLaunchKernelGGL(k_factor_tiles, dim3(1), dim3(1024), 0, c->stream, c->fv, c->nvox);   // (the table lives in the new allocation)
   c->cap = newcap;
   return VBA_OK;
 }
@@ -253,7 +253,7 @@ int factor_reserve(vba_ctx *c, int need) {
 void factor_update_mask(vba_ctx *c, int base, int n) {
   if (n > 0) hipLaunchKernelGGL(k_factor_mask, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fv, base, n);
   // the Hessian pass' tile table of the whole store [0, base + n) (vba_kernels_h3.hpp)
-  if (base + n > 0) hipLaunchKernelGGL(k_factor_tiles, dim3(1), dim3(1024), 0, c->stream, c->fv, base + n);
+  if (base + n > 0 && c->use_h3) hipLaunchKernelGGL(k_factor_tiles, dim3(1), dim3(1024), 0, c->stream, c->fv, base + n);
 }
 
 int upload_poses(vba_ctx *c, const double *poses) {
