@@ -57,6 +57,7 @@ enum { CNT_NODES = 0, CNT_FIX, CNT_SLIDE, CNT_OVERFLOW, CNT_TOUCH, CNT_ROOTS, CN
        CNT_FBLK, CNT_TAKE,         // blocks of the fixed-point pool / leaves whose oldest frame moves to the pool in this margi
        CNT_WLB, CNT_CURSOR,        // leaves of the work list with more than 64 points of the scan (their own kernel) / segment allocator of the scan
        CNT_WL, CNT_SPLIT,          // ordered accumulation: leaf segments of the scan being inserted / leaves split by the current recut level
+       CNT_DBG0, CNT_DBG1, CNT_DBG2, CNT_DBG3, // diagnostics build only (-DVBA_DIAG)
        CNT_SLIDE_G, CNT_TOUCH_G,   // the two counts the reference's 'fewer voxels than threads' quirks test, summed over the ranks when the map is sharded
        CNT_N };
 
@@ -85,8 +86,8 @@ struct MapView {
   double *nadd, *nfix, *ncov, *neval, *nevec, *nplane, *nlc;
   // scan ring
   int max_pts;
-  double *px;   // [3][W][max_pts]
-  double *pvar; // [9][W][max_pts]
+  double *px;   // [W][max_pts][3]  (AoS: the per-leaf kernels gather whole points by index)
+  double *pvar; // [W][max_pts][9]
   int *pnode;   // [W][max_pts]
   int *phash;   // [max_pts] temp
   int *newslots;  // [max_pts] temp
@@ -158,10 +159,16 @@ __device__ __forceinline__ void ord_terms(double *t, double bx, double by, doubl
       }
   }
 }
+// The sums of a node are stored NODE-MAJOR (nlc[id][slot][10], nadd / nfix[id][10], ncov[id][45]): the accumulation kernels own a
+// leaf per wave and touch all its scalars (63 consecutive-ish doubles instead of 63 cache lines), the per-node kernels read whole
+// records anyway.
+__device__ __forceinline__ double &nlc_at(const MapView &m, size_t W, int k, int slot, size_t id) { return m.nlc[(id * W + slot) * 10 + k]; }
+__device__ __forceinline__ double &nadd_at(const MapView &m, int k, size_t id) { return m.nadd[id * 10 + k]; }
+__device__ __forceinline__ double &nfix_at(const MapView &m, int k, size_t id) { return m.nfix[id * 10 + k]; }
+__device__ __forceinline__ double &ncov_at(const MapView &m, int k, size_t id) { return m.ncov[id * 45 + k]; }
 // where scalar k of a leaf lives: [0..8] nlc (slot cluster), [9..17] nadd (pcr_add), [18..62] ncov (cov_add)
-__device__ __forceinline__ double *ord_target(const MapView &m, int W, int slot, int k) {
-  const size_t cp = (size_t)m.cap;
-  return k < 9 ? m.nlc + ((size_t)k * W + slot) * cp : k < 18 ? m.nadd + (size_t)(k - 9) * cp : m.ncov + (size_t)(k - 18) * cp;
+__device__ __forceinline__ double *ord_target(const MapView &m, int W, int slot, int k, int leaf) {
+  return k < 9 ? &nlc_at(m, (size_t)W, k, slot, leaf) : k < 18 ? &nadd_at(m, k - 9, leaf) : &ncov_at(m, k - 18, leaf);
 }
 
 __device__ __forceinline__ int octant_of(const MapView &m, int node, double x, double y, double z) {
@@ -207,7 +214,8 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (!world_given) {   // the slot's previous occupant is gone: its insertion segments are cleared here (k_ins_scan writes the new ones)
     int *sa = m.nseg_a + (size_t)slot * m.cap, *sb = m.nseg_b + (size_t)slot * m.cap;
-    for (int i = p; i < m.cap; i += gridDim.x * blockDim.x) { sa[i] = 0; sb[i] = 0; }
+    const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;   // (ids that were never handed out still hold the zeros of their allocation)
+    for (int i = p; i < nn; i += gridDim.x * blockDim.x) { sa[i] = 0; sb[i] = 0; }
     int *pl = m.pleaf + (size_t)slot * m.max_pts;
     for (int i = p; i < m.max_pts; i += gridDim.x * blockDim.x) pl[i] = -1;
   }
@@ -218,7 +226,8 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
     if (world_given) {  // fixed points arrive in world coordinates, staged in the pool tail (see map_cut_voxel_fix)
       x = m.fx[(size_t)0 * m.cap_fix + slot + p]; y = m.fx[(size_t)1 * m.cap_fix + slot + p]; z = m.fx[(size_t)2 * m.cap_fix + slot + p];
     } else {
-      const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+      const double *pp = m.px + ((size_t)slot * mpz + p) * 3;
+      const double bx = pp[0], by = pp[1], bz = pp[2];
       world_point(m.poses, bx, by, bz, x, y, z);   // the scan pose is staged at poses[0..12)
     }
     const long long kx = key_axis(x, P.voxel_size), ky = key_axis(y, P.voxel_size), kz = key_axis(z, P.voxel_size);
@@ -310,84 +319,75 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, 
   atomicAdd(&m.cnt[CNT_ROOTS], 1);
 }
 
-// Phase 3: descend to the leaf (OctoTree::allocate VM:1204-1237) and count the leaf's points; the first point of a leaf puts it on
-// the work list.  Grouping by leaf needs no global sort: count -> exclusive scan over the touched leaves (their segments of perm,
-// in any order) -> scatter (arrival order inside a segment) -> the wave that owns the leaf puts its segment into scan order.
+// Phase 3: descend to the leaf (OctoTree::allocate VM:1204-1237) and count the leaf's points.  Grouping by leaf needs no global
+// sort: count -> segments of the touched leaves (in any order) -> scatter (arrival order inside a segment) -> the wave that owns
+// the leaf puts its segment into scan order.
 __global__ __launch_bounds__(256) void k_ins_leaf(MapView m, MapParams P, int slot, int n, int multi) {
-  __shared__ int wbase[4];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
-  bool first = false;
-  int node = -1;
-  if (p < n) {
-    const bool dropped = multi && touch_count(m, P) < P.thread_num;   // VM:2044-2045: the scan is dropped
-    const int h = m.phash[p];
-    node = (!dropped && h >= 0) ? m.hvals[h] : -1;
-    if (node >= 0) {
-      const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
-      double x, y, z;
-      world_point(m.poses, bx, by, bz, x, y, z);
-      while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
-      first = atomicAdd(&m.ncnt[node], 1) == 0;
-      if (first) { m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1; }
-    }
-    m.pnode[(size_t)slot * mpz + p] = node;
+  if (p >= n) return;
+  const size_t mpz = (size_t)m.max_pts;
+  const bool dropped = multi && touch_count(m, P) < P.thread_num;   // VM:2044-2045: the scan is dropped
+  const int h = m.phash[p];
+  int node = (!dropped && h >= 0) ? m.hvals[h] : -1;
+  if (node >= 0) {
+    const double *pp = m.px + ((size_t)slot * mpz + p) * 3;
+    const double bx = pp[0], by = pp[1], bz = pp[2];
+    double x, y, z;
+    world_point(m.poses, bx, by, bz, x, y, z);
+    while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
+    const int arrival = atomicAdd(&m.ncnt[node], 1);      // the point's place in its leaf's segment (arrival order)
+    if (arrival == 0) { m.f_sw[node] = 1; m.f_exist[node] = 1; m.f_touched[node] = 1; }
+    m.phash[p] = arrival;
   }
-  const unsigned long long mask = __ballot(first);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wbase[wave] = __popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int w = 0; w < 4; w++) { const int c = wbase[w]; wbase[w] = tot; tot += c; }
-    const int base = tot ? atomicAdd(&m.cnt[CNT_WL], tot) : 0;
-    for (int w = 0; w < 4; w++) wbase[w] += base;
-  }
-  __syncthreads();
-  if (first) m.wl[wbase[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = node;   // (the order of the list carries no meaning)
+  m.pnode[(size_t)slot * mpz + p] = node;
 }
 
-// Phase 4: every leaf of the work list gets its segment [nseg_a, nseg_b) of perm[slot].  The ORDER of the segments carries no meaning,
-// so no global scan is needed: a workgroup scans its 256 counts and reserves their sum with one atomic on the scan's cursor.
-// ncnt becomes the scatter cursor; leaves with more than 64 points also go onto the list of the workgroup-per-leaf kernel.
+// Phase 4: one thread per NODE; every node that counted points gets its segment [nseg_a, nseg_b) of perm[slot] and an entry of the
+// work list.  The ORDER of the segments carries no meaning, so no global scan is needed: a workgroup scans its 256 counts and
+// reserves their sum (and its run of list entries) with one atomic each.  The list comes out in runs of ascending node index:
+// neighbouring waves of the accumulation kernel then work on neighbouring leaves, whose sums share the cache lines of the
+// component-major leaf arrays.  ncnt returns to zero; leaves with more than 64 points also go onto the list of the
+// workgroup-per-leaf kernel.
 __global__ __launch_bounds__(256) void k_ins_scan(MapView m, int slot) {
-  __shared__ int wsum[4];
-  __shared__ int sbase;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int T = m.cnt[CNT_WL];
-  if (blockIdx.x * blockDim.x >= T) return;                  // (the grid covers the scan's points, an upper bound of T)
+  __shared__ int wsum[4], wnum[4];
+  __shared__ int sbase, lbase;
+  const int NN = m.cnt[CNT_NODES];
+  if ((int)(blockIdx.x * blockDim.x) >= NN) return;          // (the grid covers an upper bound of the node count)
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t cp = (size_t)m.cap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int leaf = i < T ? m.wl[i] : -1;
-  const int c = leaf >= 0 ? m.ncnt[leaf] : 0;
+  const int c = leaf < NN ? m.ncnt[leaf] : 0;
   int incl = c;
   for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  const unsigned long long mask = __ballot(c > 0);
   if (lane == 63) wsum[wave] = incl;
+  if (lane == 0) wnum[wave] = __popcll(mask);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    sbase = atomicAdd(&m.cnt[CNT_CURSOR], tot);
+    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3], num = wnum[0] + wnum[1] + wnum[2] + wnum[3];
+    sbase = num ? atomicAdd(&m.cnt[CNT_CURSOR], tot) : 0;
+    lbase = num ? atomicAdd(&m.cnt[CNT_WL], num) : 0;
   }
   __syncthreads();
-  int wb = sbase;
-  for (int w = 0; w < wave; w++) wb += wsum[w];
-  if (leaf >= 0) {
-    const int start = wb + incl - c;
+  if (c > 0) {
+    int wb = sbase, lb = lbase;
+    for (int w = 0; w < wave; w++) { wb += wsum[w]; lb += wnum[w]; }
+    const int start = wb + incl - c, i = lb + __popcll(mask & ((1ull << lane) - 1ull));
     m.nseg_a[(size_t)slot * cp + leaf] = start;
     m.nseg_b[(size_t)slot * cp + leaf] = start + c;
-    m.ncnt[leaf] = start;
+    m.ncnt[leaf] = 0;
     m.wl4[i] = make_int4(leaf, start, c, 0);
     if (c > 64) m.wlb[atomicAdd(&m.cnt[CNT_WLB], 1)] = i;   // (few)
   }
 }
 
-// Phase 5: every point takes the next free place of its leaf's segment (arrival order; the owner of the leaf orders the segment)
+// Phase 5: every point takes its place in its leaf's segment (the arrival rank k_ins_leaf drew; the owner of the leaf orders the segment)
 __global__ __launch_bounds__(256) void k_ins_scatter(MapView m, int slot, int n) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts;
   const int node = m.pnode[(size_t)slot * mpz + p];
-  if (node >= 0) m.perm[(size_t)slot * mpz + atomicAdd(&m.ncnt[node], 1)] = p;
+  if (node >= 0) m.perm[(size_t)slot * mpz + m.nseg_a[(size_t)slot * m.cap + node] + m.phash[p]] = p;
 }
 
 // one chunk of <= 64 points of a leaf in scan order: lane j prepares the terms of point j, lane k adds term k of the points in order.
@@ -399,20 +399,21 @@ __device__ __forceinline__ void ord_chunk(const MapView &m, const MapParams &P, 
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
   double t[C::NT];
   if (lane < cnt) {
-    const double bx = m.px[(0 * W + slot) * mpz + p], by = m.px[(1 * W + slot) * mpz + p], bz = m.px[(2 * W + slot) * mpz + p];
+    const double *pp = m.px + ((size_t)slot * mpz + p) * 3;
+      const double bx = pp[0], by = pp[1], bz = pp[2];
     double var[9];
     if (HAS_VAR) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)k * W + slot) * mpz + p];
+      for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)slot * mpz + p) * 9 + k];
     }
     double x, y, z;
     world_point(m.poses, bx, by, bz, x, y, z);
     ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
     // the point joins the leaf's ordered storage
-    m.sx[(0 * W + slot) * mpz + pos] = bx; m.sx[(1 * W + slot) * mpz + pos] = by; m.sx[(2 * W + slot) * mpz + pos] = bz;
+    { double *sp3 = m.sx + ((size_t)slot * mpz + pos) * 3; sp3[0] = bx; sp3[1] = by; sp3[2] = bz; }
     if (HAS_VAR) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) m.svar[((size_t)k * W + slot) * mpz + pos] = var[k];
+      for (int k = 0; k < 9; k++) m.svar[((size_t)slot * mpz + pos) * 9 + k] = var[k];
     }
     m.pleaf[(size_t)slot * mpz + pos] = leaf;
   }
@@ -431,6 +432,8 @@ __device__ __forceinline__ void ord_chunk(const MapView &m, const MapParams &P, 
 
 // Phase 6: one wave per leaf of the work list with <= 64 points — push VM:1129-1140 for the leaf's points in scan order.  The
 // segment arrives in arrival order; a point's place in scan order is the number of smaller indices in the segment (64 lane reads).
+// (Packing several small leaves into one wave was measured: no gain at any pack size — the kernel is bound by its scattered
+// 8-byte accesses, not by per-wave latency.)
 template <bool HAS_VAR>
 __global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, int slot) {
   using C = OrdCfg<HAS_VAR>;
@@ -439,14 +442,17 @@ __global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, in
   __shared__ int sp[64];
   const int lane = threadIdx.x;
   const int nseg = m.cnt[CNT_WL];
-  const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap;
-  int *perm = m.perm + (size_t)slot * mpz;
-  double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0);
-  for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+  const size_t W = (size_t)P.W;
+  int *perm = m.perm + (size_t)slot * m.max_pts;
+  // Workgroups go round-robin over the 8 XCDs (one L2 each): XCD x takes the x-th eighth of the list, so that the waves in flight on
+  // one L2 work on neighbouring list entries (neighbouring leaves).  gridDim.x is a multiple of 8.
+  const int xcd = blockIdx.x & 7, per = (nseg + 7) >> 3, s_end = (xcd + 1) * per < nseg ? (xcd + 1) * per : nseg;
+  for (int s = xcd * per + (blockIdx.x >> 3); s < s_end; s += gridDim.x >> 3) {
     const int4 e = m.wl4[s];
     const int leaf = e.x, start = e.y, cnt = e.z;
     if (cnt > 64) continue;                              // k_ins_accum_big
-    double acc = lane < C::NT ? tgt[leaf] : 0.0;
+    double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0, leaf);
+    double acc = lane < C::NT ? *tgt : 0.0;
     const int pa = lane < cnt ? perm[start + lane] : 0x7FFFFFFF;
     int rank = 0;
     for (int i = 0; i < cnt; i++) rank += (__shfl(pa, i, 64) < pa) ? 1 : 0;
@@ -455,26 +461,25 @@ __global__ __launch_bounds__(64) void k_ins_accum_ord(MapView m, MapParams P, in
     const int p = lane < cnt ? sp[lane] : 0;
     if (lane < cnt) perm[start + lane] = p;              // the segment in scan order (recut / margi read it again)
     ord_chunk<HAS_VAR>(m, P, slot, p, start + lane, leaf, cnt, lane, T, acc);
-    if (lane < C::NT) tgt[leaf] = acc;
+    if (lane < C::NT) *tgt = acc;
     if (lane == 63) {                                    // N of both clusters: integers, exact in f64
-      m.nlc[((size_t)9 * W + slot) * cp + leaf] += (double)cnt;
-      m.nadd[(size_t)9 * cp + leaf] += (double)cnt;
-      m.ncnt[leaf] = 0;
+      nlc_at(m, W, 9, slot, leaf) += (double)cnt;
+      nadd_at(m, 9, leaf) += (double)cnt;
     }
   }
 }
 
 // Leaves with more than 64 points of the scan: one workgroup per leaf.  Scan order from a BITMAP of the scan's point indices in LDS
 // (set the bits of the segment's points, count the bits below each set bit): O(n / 64 + points) whatever the segment size; scans of
-// more than `win` points are covered window by window.  Wave 0 then runs the chains chunk by chunk.
+// more than `win` points are covered window by window.
 template <bool HAS_VAR>
 __global__ __launch_bounds__(256) void k_ins_accum_big(MapView m, MapParams P, int slot, int n, int win) {
   using C = OrdCfg<HAS_VAR>;
   constexpr int TS = (HAS_VAR ? 32 : 18) | 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned long long bm[];     // [win / 64] bitmap, then [win / 64] int prefix, then T
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bm[];     // [win / 64] bitmap, then [win / 64] int prefix
   const int nw = win / 64;
   int *pre = (int *)(bm + nw);
-  double *T = (double *)(pre + nw + 2);
+  double *T = (double *)bm;                                 // the four term images of the chain phase take over the bitmap's space
   __shared__ int wsum[4];
   __shared__ int sbase;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -520,20 +525,54 @@ __global__ __launch_bounds__(256) void k_ins_accum_big(MapView m, MapParams P, i
     }
     for (int i = tid; i < cnt; i += 256) perm[start + i] = m.sval_b[start + i];
     __syncthreads();
-    // ---- the chains (wave 0)
-    if (wave == 0) {
-      double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0);
-      double acc = lane < C::NT ? tgt[leaf] : 0.0;
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int cc = cnt - c0 < 64 ? cnt - c0 : 64;
-        const int p = lane < cc ? perm[start + c0 + lane] : 0;
-        ord_chunk<HAS_VAR>(m, P, slot, p, start + c0 + lane, leaf, cc, lane, T, acc);
+    // ---- the chains: the four waves prepare the terms of four chunks of 64 points side by side (the memory trips of a chunk are
+    //      the long part), wave 0 then runs the chains through the four images in order.  The images reuse the bitmap's LDS.
+    {
+      constexpr int NR = HAS_VAR ? 2 : 1, RT = HAS_VAR ? 32 : 18;
+      double *tgt = ord_target(m, P.W, slot, lane < C::NT ? lane : 0, leaf);
+      double acc = (wave == 0 && lane < C::NT) ? *tgt : 0.0;
+      double *Tw = T + (size_t)wave * 64 * TS;
+      for (int c0 = 0; c0 < cnt; c0 += 256) {
+        const int cb = c0 + wave * 64;
+        const int cc = cnt - cb < 0 ? 0 : cnt - cb < 64 ? cnt - cb : 64;
+        double t[C::NT];
+        if (lane < cc) {
+          const int pos = start + cb + lane, p = perm[pos];
+          const double *pp = m.px + ((size_t)slot * mpz + p) * 3;
+          const double bx = pp[0], by = pp[1], bz = pp[2];
+          double var[9];
+          if (HAS_VAR) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) var[k] = m.pvar[((size_t)slot * mpz + p) * 9 + k];
+          }
+          double x, y, z;
+          world_point(m.poses, bx, by, bz, x, y, z);
+          ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
+          { double *sp3 = m.sx + ((size_t)slot * mpz + pos) * 3; sp3[0] = bx; sp3[1] = by; sp3[2] = bz; }
+          if (HAS_VAR) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) m.svar[((size_t)slot * mpz + pos) * 9 + k] = var[k];
+          }
+          m.pleaf[(size_t)slot * mpz + pos] = leaf;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          if (lane < cc) {
+#pragma unroll
+            for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) Tw[lane * TS + k] = t[r * RT + k];
+          }
+          __syncthreads();
+          if (wave == 0 && lane >= r * RT && lane < (r + 1) * RT && lane < C::NT) {
+            const int rem = cnt - c0 < 256 ? cnt - c0 : 256;                      // points of the four images, in order
+            for (int j = 0; j < rem; j++) acc += T[j * TS + (lane - r * RT)];
+          }
+          __syncthreads();
+        }
       }
-      if (lane < C::NT) tgt[leaf] = acc;
-      if (lane == 63) {
-        m.nlc[((size_t)9 * W + slot) * cp + leaf] += (double)cnt;
-        m.nadd[(size_t)9 * cp + leaf] += (double)cnt;
-        m.ncnt[leaf] = 0;
+      if (wave == 0 && lane < C::NT) *tgt = acc;
+      if (tid == 63) {
+        nlc_at(m, W, 9, slot, leaf) += (double)cnt;
+        nadd_at(m, 9, leaf) += (double)cnt;
       }
     }
     __syncthreads();
@@ -606,8 +645,8 @@ __global__ __launch_bounds__(64) void k_fix_accum_ord(MapView m, MapParams P, in
       break;
     }
     const bool store = m.nlayer[leaf] < P.max_layer;     // point_fix.push_back only below max_layer  VM:1171-1172
-    double *tgt = lane < 9 ? m.nfix + (size_t)lane * cp : m.nadd + (size_t)(lane - 9) * cp;
-    double acc = lane < 18 ? tgt[leaf] : 0.0;
+    double *tgt = lane < 9 ? &nfix_at(m, lane, leaf) : &nadd_at(m, lane < 18 ? lane - 9 : 0, leaf);
+    double acc = lane < 18 ? *tgt : 0.0;
     for (int c0 = start; c0 < end; c0 += 64) {
       const int i = c0 + lane;
       if (i < end) {
@@ -627,10 +666,10 @@ __global__ __launch_bounds__(64) void k_fix_accum_ord(MapView m, MapParams P, in
       }
       __syncthreads();
     }
-    if (lane < 18) tgt[leaf] = acc;
+    if (lane < 18) *tgt = acc;
     if (lane == 63) {
       const double dn = (double)(end - start);
-      m.nfix[(size_t)9 * cp + leaf] += dn; m.nadd[(size_t)9 * cp + leaf] += dn;
+      nfix_at(m, 9, leaf) += dn; nadd_at(m, 9, leaf) += dn;
       m.f_touched[leaf] = 1;
       if (store) fix_chain_append(m, leaf, base + start, end - start);
     }
@@ -660,13 +699,13 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
     if (multi && slide_count(m, P) < P.thread_num) break;   // VS:1693-1694
     if (!in_scope(m, P, id, multi)) break;
     m.nopt[id] = -1;
-    const double N = m.nadd[9 * cp + id];
+    const double N = nadd_at(m, 9, id);
     if (N <= P.min_point[L]) { m.f_plane[id] = 0; break; }   // VM:1406-1410
     if (!m.f_exist[id] || !m.f_sw[id]) break;                // VM:1412-1413
-    const double b0 = m.nadd[6 * cp + id] / N, b1 = m.nadd[7 * cp + id] / N, b2 = m.nadd[8 * cp + id] / N;
+    const double b0 = nadd_at(m, 6, id) / N, b1 = nadd_at(m, 7, id) / N, b2 = nadd_at(m, 8, id) / N;
     double w0, w1, w2, V[9];
-    eig3_sym_dev(m.nadd[0 * cp + id] / N - b0 * b0, m.nadd[1 * cp + id] / N - b1 * b0, m.nadd[2 * cp + id] / N - b2 * b0,
-                 m.nadd[3 * cp + id] / N - b1 * b1, m.nadd[4 * cp + id] / N - b2 * b1, m.nadd[5 * cp + id] / N - b2 * b2, w0, w1, w2, V);
+    eig3_sym_dev(nadd_at(m, 0, id) / N - b0 * b0, nadd_at(m, 1, id) / N - b1 * b0, nadd_at(m, 2, id) / N - b2 * b0,
+                 nadd_at(m, 3, id) / N - b1 * b1, nadd_at(m, 4, id) / N - b2 * b1, nadd_at(m, 5, id) / N - b2 * b2, w0, w1, w2, V);
     m.neval[id] = w0; m.neval[cp + id] = w1; m.neval[2 * cp + id] = w2;
 #pragma unroll
     for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = V[k];
@@ -688,7 +727,7 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
     m.nsplit[id] = epoch;    // the point kernels of this pass move this leaf's points to the children
     m.nstate[id] = 1;        // VM:1449
     m.f_sw[id] = 0;          // sw->clear(); sws.push_back(sw); sw = nullptr  VM:1445-1447
-    for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
+    for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)id * 10 * P.W + k] = 0.0;
     split = true;
   } while (false);
   // the leaves this level split form the work list of k_recut_push (one returning atomic per workgroup; the order carries no meaning)
@@ -707,40 +746,105 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
 }
 
 // Window points of split leaves -> children, keyed with the CURRENT poses (subdivide VM:1307-1338 + push VM:1105-1143), in the
-// reference's order: frames 0 .. win_count-1, inside a frame the leaf's points in scan order.  One wave per split leaf X.  X's points
-// of a slot are the entries with pnode == X inside the segment the slot gave to X — or to the ancestor of X that was the leaf when the
-// scan was inserted — in perm order (= scan order).  Per chunk of 64 candidates lane j prepares point j's terms; the eight children
-// are then served one after the other: lane k adds term k of the child's points, in order, to the child's scalar k (kept in LDS
-// between chunks).  The children were created empty by this level's k_recut_leaf, so every chain starts from zero like a new OctoTree.
+// reference's order: frames 0 .. win_count-1, inside a frame the leaf's points in scan order.  One WORKGROUP of four waves per split
+// leaf X (a recut level splits a few hundred to a few thousand leaves, some with thousands of points: the level lasts as long as
+// its largest leaf, so the leaf itself is spread out).  X's points of a slot are the entries with pleaf == X inside the segment the
+// slot gave to X — or to the ancestor of X that was the leaf when the scan was inserted — in scan order.  Per group of 256
+// candidates thread j prepares point j's terms (the memory trips and the arithmetic: the long part); wave w then serves children
+// 2w and 2w+1: lane k adds term k of the child's points, in order, to the child's scalar k (kept in LDS between groups).  The terms
+// are staged in rounds of 21 (LDS).  The children were created empty by this level's k_recut_leaf, so every chain starts from zero
+// like a new OctoTree.
 template <bool HAS_VAR>
-__global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int win_count, int child_layer) {
+__global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int win_count, int child_layer) {
   using C = OrdCfg<HAS_VAR>;
-  constexpr int NR = HAS_VAR ? 2 : 1, RT = HAS_VAR ? 32 : 18, TS = RT | 1;    // the terms are staged in rounds of <= 32 (LDS = occupancy here)
-  __shared__ double T[64 * TS];
+  constexpr int NR = HAS_VAR ? 3 : 1, RT = HAS_VAR ? 21 : 18, TS = RT | 1, GC = 256;   // TS odd: conflict-free rows
+  __shared__ double T[GC * TS];
   __shared__ double A[8 * 64];          // child accumulators: [0..8] body cluster of the current frame, [9..17] pcr_add, [18..62] cov_add
-  __shared__ int fj[64];
+  __shared__ unsigned long long cm[8][4];   // per child: which candidates of each of the four 64-point images are its points
+  __shared__ int fj[GC];
   __shared__ int nw[8], nb[8], nf[8], curf[8];   // per child: window points so far / points of the frame being added / fixed points / that frame
   __shared__ int fs[VBA_MAX_WIN], flen[VBA_MAX_WIN], foff[VBA_MAX_WIN + 1];   // per frame: start and length of the candidate segment; offsets in the common index space
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nsplit = m.cnt[CNT_SPLIT];
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
+  // one round of the chains over the group's images: T holds terms [r * RT, (r + 1) * RT) of the 256 candidates, cm their children
+  auto chains = [&](int r, bool framed, int base) {
+#pragma unroll 1
+    for (int cc = 0; cc < 2; cc++) {
+      const int c = 2 * wave + cc;
+      const unsigned long long k0 = cm[c][0], k1 = cm[c][1], k2 = cm[c][2], k3 = cm[c][3];
+      if ((k0 | k1 | k2 | k3) == 0ull) continue;
+      if (lane >= 9 && lane >= r * RT && lane < (r + 1) * RT && lane < C::NT) {   // pcr_add / cov_add: one chain through all frames
+        double acc = A[c * 64 + lane];
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+          unsigned long long mk = i == 0 ? k0 : i == 1 ? k1 : i == 2 ? k2 : k3;
+          while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[(i * 64 + j) * TS + lane - r * RT]; }
+        }
+        A[c * 64 + lane] = acc;
+      }
+      if (r == 0 && !framed && lane == 63) nf[c] += __popcll(k0) + __popcll(k1) + __popcll(k2) + __popcll(k3);
+      if (r == 0 && framed && (lane < 9 || lane == 63)) {       // pcrs_local: a chain per frame; lane 63 keeps the counts
+        double acc = A[c * 64 + (lane < 9 ? lane : 0)];
+        int cfr = curf[c], cnt = nb[c];
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+          unsigned long long mk = i == 0 ? k0 : i == 1 ? k1 : i == 2 ? k2 : k3;
+          while (mk) {
+            const int j = __ffsll((long long)mk) - 1; mk &= mk - 1;
+            const int fjj = fj[i * 64 + j];
+            if (fjj != cfr) {
+              if (cfr >= 0 && cnt > 0) {
+                if (lane < 9) nlc_at(m, W, lane, P.mp[cfr], base + c) = acc;
+                else nlc_at(m, W, 9, P.mp[cfr], base + c) = (double)cnt;
+              }
+              acc = 0.0; cnt = 0; cfr = fjj;
+            }
+            if (lane < 9) acc += T[(i * 64 + j) * TS + lane];
+            cnt++;
+          }
+        }
+        if (lane < 9) A[c * 64 + lane] = acc;
+        else { curf[c] = cfr; nb[c] = cnt; nw[c] += __popcll(k0) + __popcll(k1) + __popcll(k2) + __popcll(k3); }
+      }
+    }
+  };
+  // the group's terms go through T round by round; `child` < 0 = not a point of X
+  auto rounds = [&](const double *t, int child, bool framed, int base) {
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int c = 0; c < 8; c++) { const unsigned long long b = __ballot(child == c); if (lane == c) mine = b; }
+    if (lane < 8) cm[lane][wave] = mine;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      if (child >= 0) {
+#pragma unroll
+        for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) T[tid * TS + k] = t[r * RT + k];
+      }
+      __syncthreads();
+      chains(r, framed, base);
+      __syncthreads();
+    }
+  };
   for (int s = blockIdx.x; s < nsplit; s += gridDim.x) {
     const int X = m.nsl[s];
     const int base = m.nchild[X];
-#pragma unroll
-    for (int c = 0; c < 8; c++) A[c * 64 + lane] = 0.0;
-    if (lane < 8) { nw[lane] = 0; nf[lane] = 0; }
+    for (int i = tid; i < 8 * 64; i += GC) A[i] = 0.0;
+    if (tid < 8) { nw[tid] = 0; nf[tid] = 0; }
     __syncthreads();
     // ---- fix_divide (VM:1270-1299) + push_fix (VM:1149-1162): X's fixed points in point_fix order = the chains of X's ancestors
     //      (blocks that arrived while the ancestor was the leaf), oldest ancestor first, then X's own chain; entries with fnode == X
-    if (m.nfix[(size_t)9 * cp + X] != 0.0) {               // VM:1433: if (pcr_fix.N != 0)
+    if (nfix_at(m, 9, X) != 0.0) {               // VM:1433: if (pcr_fix.N != 0)
       int path[8], np = 0;
       for (int a = X; a >= 0 && np < 8; a = m.nparent[a]) path[np++] = a;
       for (int pi = np - 1; pi >= 0; pi--) {
         for (int blk = m.nfb_head[path[pi]]; blk >= 0; blk = m.fb_next[blk]) {
           const int qb = m.fb_base[blk], qe = qb + m.fb_len[blk];
-          for (int c0 = qb; c0 < qe; c0 += 64) {
-            const int q = c0 + lane;
+#ifdef VBA_DIAG
+          if (tid == 0) { atomicAdd(&m.cnt[CNT_DBG2], 1); atomicAdd(&m.cnt[CNT_DBG3], qe - qb); }
+#endif
+          for (int c0 = qb; c0 < qe; c0 += GC) {
+            const int q = c0 + tid;
             int child = -1;
             double t[C::NT];
             if (q < qe && m.fnode[q] == X) {
@@ -754,53 +858,36 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
               ord_terms<HAS_VAR>(t, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
               m.fnode[q] = (child_layer < P.max_layer) ? base + child : -1;          // VM:1152-1153
             }
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-              if (child >= 0) {
-#pragma unroll
-                for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) T[lane * TS + k] = t[r * RT + k];
-              }
-              __syncthreads();
-#pragma unroll 1
-              for (int c = 0; c < 8; c++) {
-                unsigned long long mk = __ballot(child == c);
-                if (mk == 0ull) continue;
-                if (r == 0 && lane == 63) nf[c] += __popcll(mk);
-                if (lane >= 9 && lane >= r * RT && lane < (r + 1) * RT && lane < C::NT) {
-                  double acc = A[c * 64 + lane];
-                  while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * TS + lane - r * RT]; }
-                  A[c * 64 + lane] = acc;
-                }
-              }
-              __syncthreads();
-            }
+            rounds(t, child, false, base);
           }
         }
       }
       // pcr_fix of the children = the state of the pcr_add chains after the fixed points
-#pragma unroll 1
-      for (int c = 0; c < 8; c++) {
+      for (int c = wave; c < 8; c += 4) {
         if (nf[c] == 0) continue;
-        if (lane >= 9 && lane < 18) m.nfix[(size_t)(lane - 9) * cp + base + c] = A[c * 64 + lane];
-        if (lane == 63) m.nfix[(size_t)9 * cp + base + c] = (double)nf[c];
+        if (lane >= 9 && lane < 18) nfix_at(m, lane - 9, base + c) = A[c * 64 + lane];
+        if (lane == 63) nfix_at(m, 9, base + c) = (double)nf[c];
       }
     }
     // ---- subdivide (VM:1307-1338): the frames' candidate entries form ONE index space [0, total) in frame order, so short segments
-    //      share a chunk of 64 and the memory trips of the frames overlap instead of following each other
-    if (lane < win_count) {
-      const int slot = P.mp[lane];
+    //      share a group and the memory trips of the frames overlap instead of following each other
+    if (tid < win_count) {
+      const int slot = P.mp[tid];
       int anc = X;                       // the node that was the leaf when this slot's scan was inserted
       while (anc >= 0 && m.nseg_b[(size_t)slot * cp + anc] == m.nseg_a[(size_t)slot * cp + anc]) anc = m.nparent[anc];
-      fs[lane] = anc >= 0 ? m.nseg_a[(size_t)slot * cp + anc] : 0;
-      flen[lane] = anc >= 0 ? m.nseg_b[(size_t)slot * cp + anc] - fs[lane] : 0;
+      fs[tid] = anc >= 0 ? m.nseg_a[(size_t)slot * cp + anc] : 0;
+      flen[tid] = anc >= 0 ? m.nseg_b[(size_t)slot * cp + anc] - fs[tid] : 0;
     }
-    if (lane < 8) { curf[lane] = -1; nb[lane] = 0; }
+    if (tid < 8) { curf[tid] = -1; nb[tid] = 0; }
     __syncthreads();
-    if (lane == 0) { int o = 0; for (int k = 0; k < win_count; k++) { foff[k] = o; o += flen[k]; } foff[win_count] = o; }
+    if (tid == 0) { int o = 0; for (int k = 0; k < win_count; k++) { foff[k] = o; o += flen[k]; } foff[win_count] = o; }
     __syncthreads();
     const int total = foff[win_count];
-    for (int c0 = 0; c0 < total; c0 += 64) {
-      const int tpos = c0 + lane;
+#ifdef VBA_DIAG
+    if (tid == 0) atomicAdd(&m.cnt[CNT_DBG0], total);
+#endif
+    for (int c0 = 0; c0 < total; c0 += GC) {
+      const int tpos = c0 + tid;
       int child = -1, f = 0;
       double t[C::NT];
       if (tpos < total) {
@@ -808,77 +895,38 @@ __global__ __launch_bounds__(64) void k_recut_push(MapView m, MapParams P, int w
         const int slot = P.mp[f];
         const size_t p = (size_t)(fs[f] + (tpos - foff[f]));      // position in the slot's ordered storage: no indirection
         if (m.pleaf[(size_t)slot * mpz + p] == X) {
-          const double bx = m.sx[(0 * W + slot) * mpz + p], by = m.sx[(1 * W + slot) * mpz + p], bz = m.sx[(2 * W + slot) * mpz + p];
+          const double *sp3 = m.sx + ((size_t)slot * mpz + p) * 3;
+          const double bx = sp3[0], by = sp3[1], bz = sp3[2];
           double var[9];
           if (HAS_VAR) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) var[k] = m.svar[((size_t)k * W + slot) * mpz + p];
+            for (int k = 0; k < 9; k++) var[k] = m.svar[((size_t)slot * mpz + p) * 9 + k];
           }
           double x, y, z;
           world_point(m.poses + 12 * f, bx, by, bz, x, y, z);
           child = octant_of(m, X, x, y, z);
           ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
           m.pleaf[(size_t)slot * mpz + p] = base + child;
+#ifdef VBA_DIAG
+          atomicAdd(&m.cnt[CNT_DBG1], 1);
+#endif
         }
       }
-      fj[lane] = f;
-#pragma unroll
-      for (int r = 0; r < NR; r++) {
-      if (child >= 0) {
-#pragma unroll
-        for (int k = 0; k < RT; k++) if (r * RT + k < C::NT) T[lane * TS + k] = t[r * RT + k];
-      }
-      __syncthreads();
-#pragma unroll 1
-      for (int c = 0; c < 8; c++) {
-        const unsigned long long mk0 = __ballot(child == c);
-        if (mk0 == 0ull) continue;
-        if (lane >= 9 && lane >= r * RT && lane < (r + 1) * RT && lane < C::NT) {   // pcr_add / cov_add: one chain through all frames
-          double acc = A[c * 64 + lane];
-          unsigned long long mk = mk0;
-          while (mk) { const int j = __ffsll((long long)mk) - 1; mk &= mk - 1; acc += T[j * TS + lane - r * RT]; }
-          A[c * 64 + lane] = acc;
-        }
-        if (r == 0 && (lane < 9 || lane == 63)) {              // pcrs_local: a chain per frame; lane 63 keeps the counts
-          double acc = A[c * 64 + (lane < 9 ? lane : 0)];
-          int cfr = curf[c], cnt = nb[c];
-          unsigned long long mk = mk0;
-          while (mk) {
-            const int j = __ffsll((long long)mk) - 1; mk &= mk - 1;
-            const int fjj = fj[j];
-            if (fjj != cfr) {
-              if (cfr >= 0 && cnt > 0) {
-                if (lane < 9) m.nlc[((size_t)lane * W + P.mp[cfr]) * cp + base + c] = acc;
-                else m.nlc[((size_t)9 * W + P.mp[cfr]) * cp + base + c] = (double)cnt;
-              }
-              acc = 0.0; cnt = 0; cfr = fjj;
-            }
-            if (lane < 9) acc += T[j * TS + lane];
-            cnt++;
-          }
-          if (lane < 9) A[c * 64 + lane] = acc;
-          else { curf[c] = cfr; nb[c] = cnt; nw[c] += __popcll(mk0); }
-        }
-      }
-      __syncthreads();
-      }
+      fj[tid] = f;
+      rounds(t, child, true, base);
     }
-    // the last frame of every child
-#pragma unroll 1
-    for (int c = 0; c < 8; c++) {
+    // the last frame of every child, then the children's world sums
+    for (int c = wave; c < 8; c += 4) {
       const int cfr = curf[c];
-      if (cfr < 0 || nb[c] == 0) continue;
-      if (lane < 9) m.nlc[((size_t)lane * W + P.mp[cfr]) * cp + base + c] = A[c * 64 + lane];
-      if (lane == 9) m.nlc[((size_t)9 * W + P.mp[cfr]) * cp + base + c] = (double)nb[c];
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < 8; c++) {
+      if (cfr >= 0 && nb[c] > 0) {
+        if (lane < 9) nlc_at(m, W, lane, P.mp[cfr], base + c) = A[c * 64 + lane];
+        if (lane == 9) nlc_at(m, W, 9, P.mp[cfr], base + c) = (double)nb[c];
+      }
       if (nw[c] + nf[c] == 0) continue;
       const int ch = base + c;
-      if (lane >= 9 && lane < C::NT) ord_target(m, P.W, 0, lane)[ch] = A[c * 64 + lane];
+      if (lane >= 9 && lane < C::NT) *ord_target(m, P.W, 0, lane, ch) = A[c * 64 + lane];
       if (lane == 63) {
-        m.nadd[(size_t)9 * cp + ch] = (double)(nw[c] + nf[c]);
+        nadd_at(m, 9, ch) = (double)(nw[c] + nf[c]);
         m.f_touched[ch] = 1;
         if (nw[c] > 0) { m.f_sw[ch] = 1; m.f_exist[ch] = 1; }     // push attaches a SlideWindow and sets isexist (VM:1110-1125); push_fix does neither
       }
@@ -934,7 +982,7 @@ __global__ __launch_bounds__(256) void k_extract_key(MapView m, MapParams P, int
     const int id = m.nflist[a];
     const size_t cp = (size_t)m.cap, W = (size_t)P.W;
     unsigned int key = 0;
-    for (int i = 0; i < P.W && i < 10; i++) key |= (m.nlc[((size_t)9 * W + P.mp[i]) * cp + id] != 0.0) ? (1u << i) : 0u;
+    for (int i = 0; i < P.W && i < 10; i++) key |= (nlc_at(m, W, 9, P.mp[i], id) != 0.0) ? (1u << i) : 0u;
     key = (unsigned int)mask_bucket(key, P.W < 10 ? P.W : 10);   // order of the store: popcount DESCENDING, then the mask (heavy tiles of the Hessian pass first)
     m.nfkey[a] = key;
     m.nfl2[a] = id;
@@ -976,25 +1024,53 @@ __global__ __launch_bounds__(256) void k_extract_scatter(MapView m, int nfac, in
   }
 }
 // pass 2: write the SoA factor store (push_voxel VM:139-147), frames in ring order pcrs[i] = pcrs_local[mp[i]] VM:1623-1624.
-// One thread per (factor, row of the voxel's SoA record): rows 0..10W-1 = the body clusters, then fix (10), pcr (10), coe,
-// eigval (3), eigvec (9).  (One thread per node copying all 10W+33 scalars was latency-bound: 58 us for 26k factors; one
-// thread per (NODE, row) re-derived the node's eligibility 10W+33 times over every node: 36 us.)
-__global__ void k_extract_write(MapView m, MapParams P, FactorView f, int nfac) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;       // factor index; the leaf comes from the list k_extract_count wrote
-  if (a >= nfac || a >= f.vs) return;
-  const int id = m.nflist[a];
-  const size_t cp = (size_t)m.cap, vs = (size_t)f.vs, W = (size_t)P.W;
-  const int row = blockIdx.y, ncl = 10 * P.W;
-  if (row < ncl) {
-    const int k = row / P.W, i = row - k * P.W;
-    f.cl[((size_t)k * W + i) * vs + a] = m.nlc[((size_t)k * W + P.mp[i]) * cp + id];
-  } else {
-    const int r = row - ncl;
-    if (r < 10) f.fix[(size_t)r * vs + a] = m.nfix[(size_t)r * cp + id];
-    else if (r < 20) f.pcr[(size_t)(r - 10) * vs + a] = m.nadd[(size_t)(r - 10) * cp + id];
-    else if (r == 20) f.coe[a] = 1.0;   // VM:1619
-    else if (r < 24) f.eigval[(size_t)(r - 21) * vs + a] = m.neval[(size_t)(r - 21) * cp + id];
-    else f.eigvec[(size_t)(r - 24) * vs + a] = m.nevec[(size_t)(r - 24) * cp + id];
+// A node's record (body clusters of all slots, fix, pcr) is contiguous, the store is component-major: a workgroup moves 32 factors
+// through an LDS tile — record-order reads (consecutive lanes, consecutive scalars of one node), factor-order writes.  Rows of a
+// factor: 0..10W-1 = the body clusters [k][i], then fix (10), pcr (10), coe, eigval (3), eigvec (9).
+constexpr int XW_F = 32;
+__global__ __launch_bounds__(256) void k_extract_write(MapView m, MapParams P, FactorView f, int nfac) {
+  extern __shared__ double xw_buf[];                          // [NR][XW_F + 1]
+  __shared__ int ids[XW_F];
+  __shared__ int inv[VBA_MAX_WIN];
+  const size_t cp = (size_t)m.cap, vs = (size_t)f.vs;
+  const int W = P.W, ncl = 10 * W, NR = ncl + 33;
+  const int a0 = blockIdx.x * XW_F;
+  int nf = nfac < (int)f.vs ? nfac : (int)f.vs;
+  nf = nf - a0 < XW_F ? nf - a0 : XW_F;
+  if (nf <= 0) return;
+  if (threadIdx.x < nf) ids[threadIdx.x] = m.nflist[a0 + threadIdx.x];
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + W) inv[P.mp[threadIdx.x - 64]] = threadIdx.x - 64;     // slot -> place in the ring
+  __syncthreads();
+  for (int e = threadIdx.x; e < nf * NR; e += 256) {
+    const int j = e / NR, q = e - j * NR;
+    const size_t id = (size_t)ids[j];
+    double v; int row = q;
+    if (q < ncl) { const int s = q / 10, k = q - 10 * s; v = m.nlc[id * ncl + q]; row = k * W + inv[s]; }
+    else {
+      const int r = q - ncl;
+      if (r < 10) v = nfix_at(m, r, id);
+      else if (r < 20) v = nadd_at(m, r - 10, id);
+      else if (r == 20) v = 1.0;                              // coe  VM:1619
+      else if (r < 24) v = m.neval[(size_t)(r - 21) * cp + id];
+      else v = m.nevec[(size_t)(r - 24) * cp + id];
+    }
+    xw_buf[row * (XW_F + 1) + j] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NR * XW_F; e += 256) {
+    const int row = e / XW_F, j = e - row * XW_F;
+    if (j >= nf) continue;
+    const double v = xw_buf[row * (XW_F + 1) + j];
+    const size_t a = (size_t)(a0 + j);
+    if (row < ncl) f.cl[(size_t)row * vs + a] = v;
+    else {
+      const int r = row - ncl;
+      if (r < 10) f.fix[(size_t)r * vs + a] = v;
+      else if (r < 20) f.pcr[(size_t)(r - 10) * vs + a] = v;
+      else if (r == 20) f.coe[a] = v;
+      else if (r < 24) f.eigval[(size_t)(r - 21) * vs + a] = v;
+      else f.eigvec[(size_t)(r - 24) * vs + a] = v;
+    }
   }
 }
 
@@ -1011,7 +1087,7 @@ __device__ __forceinline__ void plane_update_dev(const MapView &m, int id, const
   const size_t cp = (size_t)m.cap;
   double cv[45];                                           // cov_add, upper triangle of the symmetric 9x9
 #pragma unroll
-  for (int k = 0; k < 45; k++) cv[k] = m.ncov[(size_t)k * cp + id];
+  for (int k = 0; k < 45; k++) cv[k] = ncov_at(m, k, id);
   const double nv = 1.0 / add[9];
   const double c[3] = {add[6] * nv, add[7] * nv, add[8] * nv};
   const double u[3][3] = {{U[0], U[3], U[6]}, {U[1], U[4], U[7]}, {U[2], U[5], U[8]}};   // u[k] = column k
@@ -1122,7 +1198,7 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
   if (!m.f_exist[id] || !m.f_sw[id]) return 0;                // VM:1471-1472
   const size_t cp = (size_t)m.cap, W = (size_t)P.W, vs = (size_t)f.vs;
   double add[10], fix[10], pw0[10], ev[3], U[9], lc[10];
-  for (int k = 0; k < 10; k++) fix[k] = m.nfix[(size_t)k * cp + id];
+  for (int k = 0; k < 10; k++) fix[k] = nfix_at(m, k, id);
   for (int k = 0; k < 3; k++) ev[k] = m.neval[(size_t)k * cp + id];
   for (int k = 0; k < 9; k++) U[k] = m.nevec[(size_t)k * cp + id];
   for (int k = 0; k < 10; k++) pw0[k] = 0.0;
@@ -1134,7 +1210,7 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
     for (int k = 0; k < 3; k++) ev[k] = f.eigval[(size_t)k * vs + opt];
     for (int k = 0; k < 9; k++) U[k] = f.eigvec[(size_t)k * vs + opt];
     m.nopt[id] = -1;
-    for (int k = 0; k < 10; k++) lc[k] = m.nlc[((size_t)k * W + slot0) * cp + id];
+    for (int k = 0; k < 10; k++) lc[k] = nlc_at(m, W, k, slot0, id);
     if (lc[9] != 0.0) cluster_transform_dev(lc, m.poses, pw0);
   } else {                                                  // VM:1510-1529
     for (int k = 0; k < 10; k++) add[k] = fix[k];
@@ -1144,7 +1220,7 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
     {
       double nn[VBA_MAX_WIN_DEV];
 #pragma unroll
-      for (int i = 0; i < VBA_MAX_WIN_DEV; i++) nn[i] = (i < win_count) ? m.nlc[((size_t)9 * W + P.mp[i < win_count ? i : 0]) * cp + id] : 0.0;
+      for (int i = 0; i < VBA_MAX_WIN_DEV; i++) nn[i] = (i < win_count) ? nlc_at(m, W, 9, P.mp[i < win_count ? i : 0], id) : 0.0;
 #pragma unroll
       for (int i = 0; i < VBA_MAX_WIN_DEV; i++) occm |= (nn[i] != 0.0) ? (1u << i) : 0u;
     }
@@ -1153,7 +1229,7 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
       const int i = __ffs((int)occm) - 1;
       occm &= occm - 1;
       const int slot = smp[i];
-      for (int k = 0; k < 10; k++) lc[k] = m.nlc[((size_t)k * W + slot) * cp + id];
+      for (int k = 0; k < 10; k++) lc[k] = nlc_at(m, W, k, slot, id);
       double t[10];
       cluster_transform_dev(lc, m.poses + 12 * i, t);
       for (int k = 0; k < 10; k++) add[k] += t[k];
@@ -1181,8 +1257,8 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
     m.nclear[id] = epoch;                                   // PVec().swap(point_fix)
     m.nfb_head[id] = -1; m.nfb_tail[id] = -1;               // (entries it owns inside older blocks are released by k_margi_fixclear)
   }
-  for (int k = 0; k < 10; k++) { m.nadd[(size_t)k * cp + id] = add[k]; m.nfix[(size_t)k * cp + id] = fix[k]; }
-  for (int k = 0; k < 10; k++) m.nlc[((size_t)k * W + slot0) * cp + id] = 0.0;   // VM:1569-1574
+  for (int k = 0; k < 10; k++) { nadd_at(m, k, id) = add[k]; nfix_at(m, k, id) = fix[k]; }
+  for (int k = 0; k < 10; k++) nlc_at(m, W, k, slot0, id) = 0.0;   // VM:1569-1574
   m.f_exist[id] = (fix[9] >= add[9]) ? 0 : 1;               // VM:1577-1580
   return take;
 }
@@ -1214,11 +1290,12 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
         const int o = off + __popcll(mk & ((1ull << lane) - 1ull));
         if (o < count) {
           const int q = qb + o;
-          const double bx = m.sx[(0 * W + slot) * mpz + p], by = m.sx[(1 * W + slot) * mpz + p], bz = m.sx[(2 * W + slot) * mpz + p];
+          const double *sp3 = m.sx + ((size_t)slot * mpz + p) * 3;
+          const double bx = sp3[0], by = sp3[1], bz = sp3[2];
           double wx, wy, wz;
           world_point(m.poses, bx, by, bz, wx, wy, wz);                    // pv.pnt = x_buf[0].R * pv.pnt + x_buf[0].p  VM:1551
           m.fx[q] = wx; m.fx[cf + q] = wy; m.fx[2 * cf + q] = wz;
-          for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.svar[((size_t)k * W + slot) * mpz + p] : 0.0;
+          for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.svar[((size_t)slot * mpz + p) * 9 + k] : 0.0;
           m.fnode[q] = X;
         }
       }
@@ -1270,7 +1347,7 @@ __global__ void k_margi_clear_nodes(MapView m, MapParams P, int epoch) {
   if (id >= nn) return;
   if (m.nlayer[id] < 0 || m.ndead[m.nroot[id]] != epoch || !m.f_sw[id]) return;
   const size_t cp = (size_t)m.cap;
-  for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)k * cp + id] = 0.0;
+  for (int k = 0; k < 10 * P.W; k++) m.nlc[(size_t)id * 10 * P.W + k] = 0.0;
   m.f_sw[id] = 0;
 }
 __global__ void k_margi_clear_points(MapView m, MapParams P, int epoch) {
@@ -1330,11 +1407,11 @@ __global__ void k_prune_zero(MapView m, int W, int epoch) {
   if (r == 0) {   // a stale flag must not make a later pass take the freed node for a live leaf (its nroot may be re-owned by then)
     m.f_exist[id] = 0; m.f_sw[id] = 0; m.f_plane[id] = 0; m.f_touched[id] = 0; m.nstate[id] = 0; m.nopt[id] = -1; m.nchild[id] = -1;
   }
-  if (r < 10) { m.nadd[(size_t)r * cp + id] = 0.0; return; }
+  if (r < 10) { nadd_at(m, r, id) = 0.0; return; }
   r -= 10;
-  if (r < 10) { m.nfix[(size_t)r * cp + id] = 0.0; return; }
+  if (r < 10) { nfix_at(m, r, id) = 0.0; return; }
   r -= 10;
-  if (r < 45) { m.ncov[(size_t)r * cp + id] = 0.0; return; }
+  if (r < 45) { ncov_at(m, r, id) = 0.0; return; }
   r -= 45;
   if (r < 3) { m.neval[(size_t)r * cp + id] = 0.0; return; }
   r -= 3;
@@ -1342,7 +1419,7 @@ __global__ void k_prune_zero(MapView m, int W, int epoch) {
   r -= 9;
   if (r < 43) { m.nplane[(size_t)r * cp + id] = 0.0; return; }
   r -= 43;
-  if (r < 10 * W) { m.nlc[(size_t)r * cp + id] = 0.0; if (r < W) { m.nseg_a[(size_t)r * cp + id] = 0; m.nseg_b[(size_t)r * cp + id] = 0; } }
+  if (r < 10 * W) { m.nlc[(size_t)id * 10 * W + r] = 0.0; if (r < W) { m.nseg_a[(size_t)r * cp + id] = 0; m.nseg_b[(size_t)r * cp + id] = 0; } }
 }
 __global__ void k_prune_fix(MapView m) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1476,10 +1553,10 @@ __global__ void k_dump_leaves(MapView m, double *out, int max_leaves) {
   long long kx, ky, kz;
   unpack_key(m.nkey[id], kx, ky, kz);
   o[0] = (double)kx; o[1] = (double)ky; o[2] = (double)kz; o[3] = m.nlayer[id]; o[4] = m.npath[id];
-  o[5] = m.nadd[9 * cp + id]; o[6] = m.nfix[9 * cp + id]; o[7] = m.f_plane[id]; o[8] = m.f_exist[id]; o[9] = m.nopt[id];
+  o[5] = nadd_at(m, 9, id); o[6] = nfix_at(m, 9, id); o[7] = m.f_plane[id]; o[8] = m.f_exist[id]; o[9] = m.nopt[id];
   for (int k = 0; k < 3; k++) o[10 + k] = m.neval[(size_t)k * cp + id];
   for (int k = 0; k < 9; k++) o[13 + k] = m.nevec[(size_t)k * cp + id];
-  for (int k = 0; k < 10; k++) o[22 + k] = m.nadd[(size_t)k * cp + id];
+  for (int k = 0; k < 10; k++) o[22 + k] = nadd_at(m, k, id);
   for (int k = 0; k < 7; k++) o[32 + k] = m.nplane[(size_t)k * cp + id];
 }
 
@@ -1499,7 +1576,7 @@ __global__ void k_dump_plane_var(MapView m, double *out, int max_leaves) {
   unpack_key(m.nkey[id], kx, ky, kz);
   o[0] = (double)kx; o[1] = (double)ky; o[2] = (double)kz; o[3] = m.nlayer[id]; o[4] = m.npath[id];
   for (int k = 0; k < 36; k++) o[5 + k] = m.nplane[(size_t)(7 + k) * cp + id];
-  for (int k = 0; k < 45; k++) o[41 + k] = m.ncov[(size_t)k * cp + id];
+  for (int k = 0; k < 45; k++) o[41 + k] = ncov_at(m, k, id);
 }
 
 __global__ void k_fill_u64(unsigned long long *p, unsigned long long v, size_t n) {
@@ -1571,7 +1648,7 @@ __global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, con
   if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts;
   const double bx = pts[(size_t)p * 3], by = pts[(size_t)p * 3 + 1], bz = pts[(size_t)p * 3 + 2];
-  m.px[((size_t)0 * W + slot) * mpz + p] = bx; m.px[((size_t)1 * W + slot) * mpz + p] = by; m.px[((size_t)2 * W + slot) * mpz + p] = bz;
+  { double *pp = m.px + ((size_t)slot * mpz + p) * 3; pp[0] = bx; pp[1] = by; pp[2] = bz; }
   const double *R = pose;
   double v[9], RV[9], PR[9];
 #pragma unroll
@@ -1589,18 +1666,18 @@ __global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, con
   for (int r = 0; r < 3; r++)
 #pragma unroll
     for (int c = 0; c < 3; c++)
-      m.pvar[((size_t)(3 * r + c) * W + slot) * mpz + p] = (((RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1]) + RV[3 * r + 2] * R[3 * c + 2]) +
+      m.pvar[((size_t)slot * mpz + p) * 9 + 3 * r + c] = (((RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1]) + RV[3 * r + 2] * R[3 * c + 2]) +
                                                             ((PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1]) + PR[3 * r + 2] * ph[3 * c + 2])) + cov6[9 + 3 * r + c];
 }
 
-// AoS host layout [n][3] / [n][9] -> the scan slot's SoA arrays
+// host layout [n][3] / [n][9] -> the scan slot's staging arrays (same AoS layout)
 __global__ void k_scan_to_soa(MapView m, int W, int slot, int n, const double *pts, const double *var) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p == 0) { m.cnt[CNT_NEWSLOTS] = 0; m.cnt[CNT_TOUCH] = 0; m.cnt[CNT_WL] = 0; m.cnt[CNT_WLB] = 0; m.cnt[CNT_CURSOR] = 0; }   // the insert's counters (no kernels of their own)
   if (p >= n) return;
   const size_t mpz = (size_t)m.max_pts;
-  for (int k = 0; k < 3; k++) m.px[((size_t)k * W + slot) * mpz + p] = pts[(size_t)p * 3 + k];
-  if (var) for (int k = 0; k < 9; k++) m.pvar[((size_t)k * W + slot) * mpz + p] = var[(size_t)p * 9 + k];
+  for (int k = 0; k < 3; k++) m.px[((size_t)slot * mpz + p) * 3 + k] = pts[(size_t)p * 3 + k];
+  if (var) for (int k = 0; k < 9; k++) m.pvar[((size_t)slot * mpz + p) * 9 + k] = var[(size_t)p * 9 + k];
 }
 __global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1670,13 +1747,13 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
       {(void **)&v.nclear, 4, 1}, {(void **)&v.ndead, 4, 1}, {(void **)&v.nfree_root, 4, 1}, {(void **)&v.nfree_blk, 4, 1},
       {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.ncnt, 4, 1}, {(void **)&v.nfb_head, 4, 1}, {(void **)&v.nfb_tail, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
-      {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 8, 10}, {(void **)&v.nfix, 8, 10}, {(void **)&v.ncov, 8, 45},
-      {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, 8, (size_t)10 * W},
+      {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 80, 1}, {(void **)&v.nfix, 80, 1}, {(void **)&v.ncov, 360, 1},
+      {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, (size_t)80 * W, 1},
   };
 }
 inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
-  return {{(void **)&v.px, 8, (size_t)3 * W}, {(void **)&v.pvar, 8, (size_t)9 * W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1},
-          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.sx, 8, (size_t)3 * W}, {(void **)&v.svar, 8, (size_t)9 * W}, {(void **)&v.pleaf, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}, {(void **)&v.wlb, 4, 1}, {(void **)&v.wl4, 16, 1}};
+  return {{(void **)&v.px, 24, (size_t)W}, {(void **)&v.pvar, 72, (size_t)W}, {(void **)&v.pnode, 4, (size_t)W}, {(void **)&v.phash, 4, 1}, {(void **)&v.newslots, 4, 1},
+          {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.sx, 24, (size_t)W}, {(void **)&v.svar, 72, (size_t)W}, {(void **)&v.pleaf, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}, {(void **)&v.wlb, 4, 1}, {(void **)&v.wl4, 16, 1}};
 }
 inline std::vector<DevArr> fix_arrays(MapView &v) {
   return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}, {(void **)&v.fb_base, 4, 1}, {(void **)&v.fb_len, 4, 1}, {(void **)&v.fb_next, 4, 1}};
@@ -1900,8 +1977,6 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   }
   const MapParams P = map_params(s);
   const int nb = (n + 255) / 256;
-  if (n < s.v.max_pts)   // stale assignments of the slot's previous occupant must not survive
-    MAPCHK(hipMemsetAsync(s.v.pnode + (size_t)slot * s.v.max_pts + n, 0xFF, (size_t)(s.v.max_pts - n) * 4, st));
   if (cov6 && var) hipLaunchKernelGGL(k_scan_to_soa_pvec_update, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var, s.v.poses, s.v.poses + 16);
   else hipLaunchKernelGGL(k_scan_to_soa, dim3(nb), dim3(256), 0, st, s.v, W, slot, n, d_pts, d_var);
   s.stamp++;
@@ -1911,12 +1986,17 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   // order-preserving accumulation: leaf of every point + per-leaf counts -> segments (scan over the touched leaves) -> scatter ->
   // one wave (workgroup for big leaves) per leaf puts its segment into scan order and adds in that order
   hipLaunchKernelGGL(k_ins_leaf, dim3(nb), dim3(256), 0, st, s.v, P, slot, n, multi ? 1 : 0);
-  hipLaunchKernelGGL(k_ins_scan, dim3(nb), dim3(256), 0, st, s.v, slot);
+  {
+    long long ubn = (long long)s.ub_nodes + n;               // the insert creates at most one node (a root) per point
+    if (ubn > s.v.cap) ubn = s.v.cap;
+    hipLaunchKernelGGL(k_ins_scan, dim3((unsigned)((ubn + 255) / 256)), dim3(256), 0, st, s.v, slot);
+  }
   hipLaunchKernelGGL(k_ins_scatter, dim3(nb), dim3(256), 0, st, s.v, slot, n);
   {
-    const int nwg = n < 8192 ? n : 8192;         // grid-stride over the work list (its length stays on the device)
+    const int nwg = n < 8192 ? ((n + 7) & ~7) : 8192;   // grid-stride over the work list (its length stays on the device); a multiple of 8
     int win = 128; while (win < n && win < (1 << 19)) win *= 2;         // bitmap window of the big-leaf kernel (<= 96 KB of LDS)
-    const size_t lds_big = (size_t)(win / 64) * 12 + 16 + (size_t)64 * 33 * 8;
+    size_t lds_big = (size_t)(win / 64) * 12 + 16;
+    if (lds_big < (size_t)4 * 64 * 33 * 8) lds_big = (size_t)4 * 64 * 33 * 8;             // bitmap + prefix, then the four term images in the same space
     static bool attr_set[64] = {false};
     int dev = 0; hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
@@ -2004,9 +2084,19 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
         hipLaunchKernelGGL(k_recut_prep, dim3(1), dim3(1), 0, st, s.v.cnt);
         hipLaunchKernelGGL(k_recut_leaf, dim3(grid_nodes), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
         if (L < s.opt.max_layer) {
-          if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(64), 0, st, s.v, P, win_count, L + 1);
-          else hipLaunchKernelGGL((k_recut_push<false>), dim3(4096), dim3(64), 0, st, s.v, P, win_count, L + 1);
+          if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(256), 0, st, s.v, P, win_count, L + 1);
+          else hipLaunchKernelGGL((k_recut_push<false>), dim3(4096), dim3(256), 0, st, s.v, P, win_count, L + 1);
         }
+#ifdef VBA_DIAG
+        if (getenv("VBA_RECUT_STATS")) {
+          int h[CNT_N];
+          hipStreamSynchronize(st);
+          hipMemcpy(h, s.v.cnt, sizeof(h), hipMemcpyDeviceToHost);
+          fprintf(stderr, "[recut] level %d: nodes %d, split leaves %d, candidates scanned %d, matched %d, fix blocks walked %d (%d entries)\n", L, h[CNT_NODES], h[CNT_SPLIT], h[CNT_DBG0], h[CNT_DBG1], h[CNT_DBG2], h[CNT_DBG3]);
+          const int z[4] = {0, 0, 0, 0};
+          hipMemcpy(s.v.cnt + CNT_DBG0, z, sizeof(z), hipMemcpyHostToDevice);
+        }
+#endif
       }
       // tras_opt pass 1 rides in the same submission: one counter read-back serves the overflow check and the factor count
       r = map_set_counter(s, st, CNT_FACTORS, 0, err); if (r) return r;
@@ -2038,7 +2128,7 @@ inline int map_extract_factors(MapStore &s, hipStream_t st, FactorView f, std::s
     hipLaunchKernelGGL(k_extract_scan, dim3(1), dim3(1024), 0, st, s.v, nbuckets);
     hipLaunchKernelGGL(k_extract_scatter, dim3((nfac + 255) / 256), dim3(256), 0, st, s.v, nfac, nbuckets);
   }
-  if (nfac > 0) hipLaunchKernelGGL(k_extract_write, dim3((nfac + 255) / 256, 10 * s.opt.win_size + 33), dim3(256), 0, st, s.v, P, f, nfac);
+  if (nfac > 0) hipLaunchKernelGGL(k_extract_write, dim3((nfac + XW_F - 1) / XW_F), dim3(256), (size_t)(10 * s.opt.win_size + 33) * (XW_F + 1) * 8, st, s.v, P, f, nfac);
   MAPCHK(hipGetLastError());
   *n_factors = s.h_cnt[CNT_FACTORS];
   return VBA_OK;
