@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
         }
         if (!found && !restart) break;                      // a full sweep without the key, a tombstone or an EMPTY slot
       }
-      if (!found) m.cnt[CNT_OVERFLOW] = 4;                   // table full: never fall through to an unrelated slot
+      if (!found) atomicMax(&m.cnt[CNT_OVERFLOW], 4);                   // table full: never fall through to an unrelated slot
       else {
         hslot = (int)h;
         // hvals is only written by the next kernel, so a valid id here means "this root existed before the call"
@@ -305,7 +305,7 @@ __global__ void k_ins_newroots(MapView m, MapParams P, int is_fix, double jour, 
   const int h = hs & 0x3FFFFFFF;
   if (!(hs & 0x40000000)) atomicAdd(&m.cnt[CNT_USED], 1);     // a formerly EMPTY slot (a reused tombstone was counted when first claimed)
   const int id = alloc_nodes(m, CNT_FREE_ROOTS, m.nfree_root, 1);
-  if (id >= m.cap) { m.cnt[CNT_OVERFLOW] = 1; return; }
+  if (id >= m.cap) { atomicMax(&m.cnt[CNT_OVERFLOW], 1); return; }
   long long kx, ky, kz;
   const unsigned long long key = m.hkeys[h];
   unpack_key(key, kx, ky, kz);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void k_fix_heads(MapView m, int n) {       // 
 // link block [qb, qb + len) to the end of leaf's chain (one lane; a leaf is served by one wave per call)
 __device__ __forceinline__ void fix_chain_append(const MapView &m, int leaf, int qb, int len) {
   const int blk = atomicAdd(&m.cnt[CNT_FBLK], 1);
-  if (blk >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; return; }
+  if (blk >= m.cap_fix) { atomicMax(&m.cnt[CNT_OVERFLOW], 3); return; }
   m.fb_base[blk] = qb; m.fb_len[blk] = len; m.fb_next[blk] = -1;
   const int tail = m.nfb_tail[leaf];
   if (tail < 0) m.nfb_head[leaf] = blk; else m.fb_next[tail] = blk;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
     if (plane || L >= P.max_layer) break;
     // subdivide: children are created as a block of 8 (untouched octants stay empty leaves, which every traversal skips)
     const int base = alloc_nodes(m, CNT_FREE_BLOCKS, m.nfree_blk, 8);
-    if (base + 8 > m.cap) { m.cnt[CNT_OVERFLOW] = 1; break; }
+    if (base + 8 > m.cap) { atomicMax(&m.cnt[CNT_OVERFLOW], 1); break; }
     const double cx = m.ncenter[id], cy = m.ncenter[cp + id], cz = m.ncenter[2 * cp + id];
     const float ql = m.nql[id];
     for (int o = 0; o < 8; o++) {
@@ -762,6 +762,8 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
   __shared__ double A[8 * 64];          // child accumulators: [0..8] body cluster of the current frame, [9..17] pcr_add, [18..62] cov_add
   __shared__ unsigned long long cm[8][4];   // per child: which candidates of each of the four 64-point images are its points
   __shared__ int fj[GC];
+  constexpr int FBL = 128;
+  __shared__ int fbq[FBL], fbo[FBL + 1], fbn[2];   // blocks of X's fixed points (pool start, offset in the common index space), their number, 'more to come'
   __shared__ int nw[8], nb[8], nf[8], curf[8];   // per child: window points so far / points of the frame being added / fixed points / that frame
   __shared__ int fs[VBA_MAX_WIN], flen[VBA_MAX_WIN], foff[VBA_MAX_WIN + 1];   // per frame: start and length of the candidate segment; offsets in the common index space
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -835,19 +837,37 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
     // ---- fix_divide (VM:1270-1299) + push_fix (VM:1149-1162): X's fixed points in point_fix order = the chains of X's ancestors
     //      (blocks that arrived while the ancestor was the leaf), oldest ancestor first, then X's own chain; entries with fnode == X
     if (nfix_at(m, 9, X) != 0.0) {               // VM:1433: if (pcr_fix.N != 0)
-      int path[8], np = 0;
-      for (int a = X; a >= 0 && np < 8; a = m.nparent[a]) path[np++] = a;
-      for (int pi = np - 1; pi >= 0; pi--) {
-        for (int blk = m.nfb_head[path[pi]]; blk >= 0; blk = m.fb_next[blk]) {
-          const int qb = m.fb_base[blk], qe = qb + m.fb_len[blk];
+      // thread 0 walks the chains (one dependent load per block) and lists the blocks; their entries then form ONE index space, so
+      // that a leaf with many short blocks pays the memory trips and the chain rounds once per 256 entries, not once per block
+      int path[8], np = 0, pi = 0, blk = -1;
+      if (tid == 0) {
+        for (int a = X; a >= 0 && np < 8; a = m.nparent[a]) path[np++] = a;
+        pi = np - 1; blk = m.nfb_head[path[pi]];
+      }
+      while (true) {
+        if (tid == 0) {
+          int nbk = 0, o = 0;
+          while (nbk < FBL && pi >= 0) {
+            if (blk < 0) { pi--; if (pi >= 0) blk = m.nfb_head[path[pi]]; continue; }
+            fbq[nbk] = m.fb_base[blk]; fbo[nbk] = o; o += m.fb_len[blk]; nbk++;
+            blk = m.fb_next[blk];
+          }
+          fbo[nbk] = o; fbn[0] = nbk; fbn[1] = pi >= 0 ? 1 : 0;
+        }
+        __syncthreads();
+        const int nbk = fbn[0], ftotal = fbo[nbk], more = fbn[1];
 #ifdef VBA_DIAG
-          if (tid == 0) { atomicAdd(&m.cnt[CNT_DBG2], 1); atomicAdd(&m.cnt[CNT_DBG3], qe - qb); }
+        if (tid == 0) { atomicAdd(&m.cnt[CNT_DBG2], nbk); atomicAdd(&m.cnt[CNT_DBG3], ftotal); }
 #endif
-          for (int c0 = qb; c0 < qe; c0 += GC) {
-            const int q = c0 + tid;
-            int child = -1;
-            double t[C::NT];
-            if (q < qe && m.fnode[q] == X) {
+        for (int c0 = 0; c0 < ftotal; c0 += GC) {
+          const int tpos = c0 + tid;
+          int child = -1;
+          double t[C::NT];
+          if (tpos < ftotal) {
+            int lo = 0, hi = nbk - 1;                   // the block of entry tpos: last b with fbo[b] <= tpos
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (fbo[mid] <= tpos) lo = mid; else hi = mid - 1; }
+            const int q = fbq[lo] + (tpos - fbo[lo]);
+            if (m.fnode[q] == X) {
               const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
               double var[9];
               if (HAS_VAR) {
@@ -858,9 +878,11 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
               ord_terms<HAS_VAR>(t, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
               m.fnode[q] = (child_layer < P.max_layer) ? base + child : -1;          // VM:1152-1153
             }
-            rounds(t, child, false, base);
           }
+          rounds(t, child, false, base);
         }
+        __syncthreads();                                  // (the block list is rewritten by the next batch)
+        if (!more) break;
       }
       // pcr_fix of the children = the state of the pcr_add chains after the fixed points
       for (int c = wave; c < 8; c += 4) {
@@ -1181,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_margi_leaf(MapView m, MapParams P, Fact
     const int qb = bases[2] + wcnt[wave] + incl - count;
     const int blk = bases[1] + r;
     m.nsl[bases[0] + r] = id; m.wl[bases[0] + r] = qb; m.wlb[bases[0] + r] = count;
-    if (qb + count > m.cap_fix || blk >= m.cap_fix) { m.cnt[CNT_OVERFLOW] = 3; m.wlb[bases[0] + r] = 0; }
+    if (qb + count > m.cap_fix || blk >= m.cap_fix) { atomicMax(&m.cnt[CNT_OVERFLOW], 3); m.wlb[bases[0] + r] = 0; }
     else {                                                 // link the block to the leaf's chain (this thread owns the leaf)
       m.fb_base[blk] = qb; m.fb_len[blk] = count; m.fb_next[blk] = -1;
       const int tail = m.nfb_tail[id];
@@ -1203,7 +1225,7 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
   for (int k = 0; k < 9; k++) U[k] = m.nevec[(size_t)k * cp + id];
   for (int k = 0; k < 10; k++) pw0[k] = 0.0;
   const int opt = m.nopt[id];
-  if (opt >= nfac) { m.cnt[CNT_OVERFLOW] = 2; return 0; }     // VM:1488-1492 "Error: opt_state"
+  if (opt >= nfac) { atomicMax(&m.cnt[CNT_OVERFLOW], 2); return 0; }     // VM:1488-1492 "Error: opt_state"
   const int slot0 = P.mp[0];
   if (opt >= 0) {                                           // VM:1495-1509
     for (int k = 0; k < 10; k++) add[k] = f.pcr[(size_t)k * vs + opt];
@@ -1690,7 +1712,14 @@ __global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
 
 // ================================================================================================ host side
 __global__ void k_set_counter(int *cnt, int which, int val) { cnt[which] = val; }
-__global__ void k_recut_prep(int *cnt) { cnt[CNT_SNAP] = cnt[CNT_NODES]; cnt[CNT_SPLIT] = 0; }   // per recut level: node snapshot, empty split list
+__global__ void k_set_counter2(int *cnt, int a, int va, int b, int vb) { cnt[a] = va; cnt[b] = vb; }
+// per recut level: node snapshot, empty split list; the first level clears the overflow flag (a full hash table reported by an
+// insertion, code 4, stays up for the read-back at the end of the pass), the last one the factor counter of k_extract_count
+__global__ void k_recut_prep(int *cnt, int first, int last) {
+  cnt[CNT_SNAP] = cnt[CNT_NODES]; cnt[CNT_SPLIT] = 0;
+  if (first && cnt[CNT_OVERFLOW] != 4) cnt[CNT_OVERFLOW] = 0;
+  if (last) cnt[CNT_FACTORS] = 0;
+}
 __global__ void k_copy_counter(int *cnt, int from, int to) { cnt[to] = cnt[from]; }
 struct DevArr {  // a [rows][cap] device array that can grow its cap keeping [rows][used]
   void **slot; size_t elem, rows;
@@ -2066,22 +2095,24 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
   if (!s.allocated) return VBA_OK;
   if (multi) { int r0 = map_global_count(s, st, CNT_SLIDE, CNT_SLIDE_G, err); if (r0) return r0; }   // VS:1693 tests surf_map_slide.size() of the whole map
   for (int attempt = 0; attempt < 8; attempt++) {
-    int r = map_read_counters(s, st, err);
-    if (r) return r;
-    if (attempt == 0 && s.h_cnt[CNT_OVERFLOW] == 4) { err = "root hash table full during scan insertion"; return VBA_ERR_CAPACITY; }
+    // The first attempt works from the host's upper bound of the node count (exact at the last read-back + the points inserted
+    // since): no read-back, hence no drain of the stream, before the pass.  The pass ends with the one read-back that serves the
+    // overflow check, the factor count and the next call's bounds.
+    int r = VBA_OK;
+    if (attempt > 0) { r = map_read_counters(s, st, err); if (r) return r; }
+    const size_t nodes_ub = attempt ? (size_t)s.h_cnt[CNT_NODES] : (size_t)s.ub_nodes;
     // room for every current leaf to split once per level (checked again through the overflow flag)
-    r = map_ensure(s, st, (size_t)s.h_cnt[CNT_NODES] + 8 * (size_t)(attempt ? s.h_cnt[CNT_NODES] : 65536), 0, 0, err);
+    r = map_ensure(s, st, nodes_ub + 8 * (size_t)(attempt ? s.h_cnt[CNT_NODES] : 65536), 0, 0, err);
     if (r) return r;
-    r = map_set_counter(s, st, CNT_OVERFLOW, 0, err); if (r) return r;
     MAPCHK(hipMemcpyAsync(s.v.poses, poses, (size_t)(win_count > 0 ? win_count : 1) * 12 * sizeof(double), hipMemcpyHostToDevice, st));
     const MapParams P = map_params(s);
     int max_n = 0;
     for (int i = 0; i < win_count; i++) if (s.npts[s.mp[i]] > max_n) max_n = s.npts[s.mp[i]];
     const int grid_nodes = (s.v.cap + 255) / 256;
-    if (s.h_cnt[CNT_NODES] > 0) {
+    if (nodes_ub > 0) {
       for (int L = 0; L <= s.opt.max_layer; L++) {
         s.epoch++;
-        hipLaunchKernelGGL(k_recut_prep, dim3(1), dim3(1), 0, st, s.v.cnt);
+        hipLaunchKernelGGL(k_recut_prep, dim3(1), dim3(1), 0, st, s.v.cnt, L == 0 ? 1 : 0, L == s.opt.max_layer ? 1 : 0);
         hipLaunchKernelGGL(k_recut_leaf, dim3(grid_nodes), dim3(256), 0, st, s.v, P, L, multi ? 1 : 0, s.epoch);
         if (L < s.opt.max_layer) {
           if (s.have_var) hipLaunchKernelGGL((k_recut_push<true>), dim3(4096), dim3(256), 0, st, s.v, P, win_count, L + 1);
@@ -2099,12 +2130,12 @@ inline int map_recut(MapStore &s, hipStream_t st, int win_count, const double *p
 #endif
       }
       // tras_opt pass 1 rides in the same submission: one counter read-back serves the overflow check and the factor count
-      r = map_set_counter(s, st, CNT_FACTORS, 0, err); if (r) return r;
       hipLaunchKernelGGL(k_extract_count, dim3(grid_nodes), dim3(256), 0, st, s.v, P, multi ? 1 : 0);
     }
     MAPCHK(hipGetLastError());
     r = map_read_counters(s, st, err);
     if (r) return r;
+    if (s.h_cnt[CNT_OVERFLOW] == 4) { err = "root hash table full during scan insertion"; return VBA_ERR_CAPACITY; }
     if (!s.h_cnt[CNT_OVERFLOW]) break;
     // a leaf could not be split for lack of node space: clamp the counter, grow and run the pass again (idempotent)
     if (s.h_cnt[CNT_NODES] > s.v.cap) { r = map_set_counter(s, st, CNT_NODES, s.v.cap, err); if (r) return r; }
@@ -2144,7 +2175,7 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   const int slot0 = s.mp[0];
   r = map_ensure(s, st, 0, 0, (size_t)s.h_cnt[CNT_FIX] + (size_t)s.npts[slot0] + 1, err);
   if (r) return r;
-  r = map_set_counter(s, st, CNT_OVERFLOW, 0, err); if (r) return r;
+  hipLaunchKernelGGL(k_set_counter2, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_OVERFLOW, 0, (int)CNT_TAKE, 0);
   MAPCHK(hipMemcpyAsync(s.v.poses, poses, (size_t)win_count * 12 * sizeof(double), hipMemcpyHostToDevice, st));
   const MapParams P = map_params(s);
   const int nn = s.h_cnt[CNT_NODES] < s.v.cap ? s.h_cnt[CNT_NODES] : s.v.cap;
@@ -2152,7 +2183,6 @@ inline int map_margi(MapStore &s, hipStream_t st, int win_count, const double *p
   if (nn == 0) return VBA_OK;
   s.epoch++;
   const dim3 gn((nn + 255) / 256), b(256);
-  hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, s.v.cnt, (int)CNT_TAKE, 0);
   hipLaunchKernelGGL(k_margi_leaf, gn, b, 0, st, s.v, P, f, nfac, win_count, s.epoch);
   if (n_slide_before >= s.opt.thread_num) {
     if (s.npts[slot0] > 0) {
