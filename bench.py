@@ -190,7 +190,10 @@ def local_mapping_step(capi, torch, wl, steps=12):
     imu_all = np.stack([capi.imu_preintegrate(t, gy, ac, np.zeros(3), np.zeros(3), nm, nw) for (t, gy, ac) in imu_samples])
     out = {}
     for name, li in (("li_ba", True), ("lidar_only", False)):
-        ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
+        o = capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream)
+        # capacity hints: a deployment sizes the map once (vba_options), so that no step stalls on a re-allocation
+        o.max_points_per_scan, o.max_map_nodes, o.max_fix_points, o.max_voxels = 1 << 18, 1 << 21, 1 << 23, 1 << 17
+        ctx = capi.Context(o)
         # body-frame covariances (calcBodyVar, VH:180-234) once per scan on the device, kept in HBM with the points
         pv = [ctx.var_init(p, ext, wl.dept_err, wl.beam_err) for p in sl["points"]]
         dev_p = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a, _ in pv]

@@ -42,6 +42,7 @@ class Options(C.Structure):
         ("imu_coef", C.c_double), ("thread_num", C.c_int), ("device", C.c_int), ("stream", C.c_void_p),
         ("max_voxels", C.c_size_t), ("max_points_per_scan", C.c_size_t),
         ("lm_spec", C.c_int), ("force_collective", C.c_int), ("hessian_workgroups", C.c_int), ("residual_vpl_from", C.c_int), ("hessian_compact_tiles", C.c_int),
+        ("max_map_nodes", C.c_size_t), ("max_fix_points", C.c_size_t),
     ]
 
 

@@ -104,8 +104,8 @@ struct MapView {
   int4 *wl4;    // [max_pts] work list entries (leaf, segment start, points, -) for the per-leaf kernels: one 16-byte load
   // fixed-point pool
   int cap_fix;
-  double *fx;   // [3][cap_fix]
-  double *fvar; // [9][cap_fix]
+  double *fx;   // [cap_fix][3]  (AoS, as the window points: a leaf's block is one contiguous run)
+  double *fvar; // [cap_fix][9]
   int *fnode;
   int *fb_base, *fb_len, *fb_next;   // [cap_fix] block table of the pool (a block has >= 1 point)
   int *sval_b;  // [max_pts] sort values out where the destination is not a slot's perm (fixed-point insertion)
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
     for (int i = p; i < m.max_pts; i += gridDim.x * blockDim.x) pl[i] = -1;
   }
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W;
-  int hslot = -1, root = -1;
+  int hslot = -1, root = -1, claimed = -1;                   // claimed: the hash slot this thread took for a new root (bit 30: a reused tombstone)
   if (p < n) {
     double x, y, z;
     if (world_given) {  // fixed points arrive in world coordinates, staged in the pool tail (see map_cut_voxel_fix)
-      x = m.fx[(size_t)0 * m.cap_fix + slot + p]; y = m.fx[(size_t)1 * m.cap_fix + slot + p]; z = m.fx[(size_t)2 * m.cap_fix + slot + p];
+      { const double *fp = m.fx + (size_t)(slot + p) * 3; x = fp[0]; y = fp[1]; z = fp[2]; }
     } else {
       const double *pp = m.px + ((size_t)slot * mpz + p) * 3;
       const double bx = pp[0], by = pp[1], bz = pp[2];
@@ -253,12 +253,12 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
           if (cur == KEY_EMPTY) {
             if (tomb >= 0) {
               const unsigned long long prev = atomicCAS(&m.hkeys[tomb], KEY_TOMB, key);
-              if (prev == KEY_TOMB) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = tomb | (int)0x40000000; h = (unsigned int)tomb; found = true; break; }
+              if (prev == KEY_TOMB) { claimed = tomb | (int)0x40000000; h = (unsigned int)tomb; found = true; break; }
               if (prev == key) { h = (unsigned int)tomb; found = true; break; }
               restart = true; break;                        // another key took the tombstone: scan again
             }
             const unsigned long long prev = atomicCAS(&m.hkeys[h], KEY_EMPTY, key);
-            if (prev == KEY_EMPTY) { const int i = atomicAdd(&m.cnt[CNT_NEWSLOTS], 1); m.newslots[i] = (int)h; found = true; break; }
+            if (prev == KEY_EMPTY) { claimed = (int)h; found = true; break; }
             if (prev == key) { found = true; break; }
             // another key took this slot: it is an ordinary occupied slot now, keep probing
           }
@@ -274,6 +274,16 @@ __global__ __launch_bounds__(256) void k_ins_keys(MapView m, MapParams P, int sl
       }
     }
     m.phash[p] = hslot;
+  }
+  {  // the new slots join the list of k_ins_newroots: one returning atomic per wave (thousands of them on one address serialise in L2)
+    const unsigned long long mc = __ballot(claimed >= 0);
+    if (mc) {
+      const int ln = threadIdx.x & 63, lead = __ffsll((long long)mc) - 1;
+      int b0 = 0;
+      if (ln == lead) b0 = atomicAdd(&m.cnt[CNT_NEWSLOTS], __popcll(mc));
+      b0 = __shfl(b0, lead, 64);
+      if (claimed >= 0) m.newslots[b0 + __popcll(mc & ((1ull << ln) - 1ull))] = claimed;
+    }
   }
   // Roots that existed before this call are marked here (isexist, sliding-map membership, per-scan touch count:
   // VM:1997-2001); roots created by this call are marked by k_ins_newroots.  Consecutive points of a scan mostly share
@@ -590,7 +600,7 @@ __global__ void k_fix_leaf(MapView m, MapParams P, int base, int n) {
   const int h = m.phash[p];
   int node = h >= 0 ? m.hvals[h] : -1;
   if (node >= 0) {
-    const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
+    const double x = m.fx[(size_t)q * 3], y = m.fx[(size_t)q * 3 + 1], z = m.fx[(size_t)q * 3 + 2];
     while (m.nstate[node] == 1) node = m.nchild[node] + octant_of(m, node, x, y, z);
   }
   m.skey_a[p] = node >= 0 ? (unsigned int)node : 0xFFFFFFFFu;
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(64) void k_fix_accum_ord(MapView m, MapParams P, in
         const int p = m.sval_b[i];
         const double x = pts[(size_t)p * 3], y = pts[(size_t)p * 3 + 1], z = pts[(size_t)p * 3 + 2];
         const int q = base + i;                      // pool entries in GROUP order: the group is one block
-        m.fx[q] = x; m.fx[cf + q] = y; m.fx[2 * cf + q] = z;
+        m.fx[(size_t)q * 3] = x; m.fx[(size_t)q * 3 + 1] = y; m.fx[(size_t)q * 3 + 2] = z;
         m.fnode[q] = store ? leaf : -1;
         double *t = T + lane * 9;
         t[0] = x * x; t[1] = x * y; t[2] = x * z; t[3] = y * y; t[4] = y * z; t[5] = z * z; t[6] = x; t[7] = y; t[8] = z;
@@ -691,6 +701,7 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
   __shared__ int wbase[4];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_SNAP] < m.cap ? m.cnt[CNT_SNAP] : m.cap;
+  if ((int)(blockIdx.x * blockDim.x) >= nn) return;         // (the grid covers the capacity, not the node count)
   const size_t cp = (size_t)m.cap;
   bool split = false;
   do {
@@ -868,11 +879,11 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (fbo[mid] <= tpos) lo = mid; else hi = mid - 1; }
             const int q = fbq[lo] + (tpos - fbo[lo]);
             if (m.fnode[q] == X) {
-              const double x = m.fx[q], y = m.fx[cf + q], z = m.fx[2 * cf + q];
+              const double x = m.fx[(size_t)q * 3], y = m.fx[(size_t)q * 3 + 1], z = m.fx[(size_t)q * 3 + 2];
               double var[9];
               if (HAS_VAR) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)k * cf + q];
+                for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)q * 9 + k];
               }
               child = octant_of(m, X, x, y, z);
               ord_terms<HAS_VAR>(t, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
@@ -963,6 +974,7 @@ __global__ __launch_bounds__(256) void k_extract_count(MapView m, MapParams P, i
   __shared__ int wbase[4];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int nn = m.cnt[CNT_NODES] < m.cap ? m.cnt[CNT_NODES] : m.cap;
+  if ((int)(blockIdx.x * blockDim.x) >= nn) return;
   bool take = id < nn && m.nstate[id] == 0;
   if (take && multi && slide_count(m, P) < P.thread_num) take = false;
   if (take && !in_scope(m, P, id, multi)) take = false;
@@ -1289,13 +1301,15 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
 // one wave per such leaf X.  X's frame-0 points are the entries with pnode == X of the segment slot mp[0] gave to X (or to the ancestor
 // that was the leaf when that scan was inserted).  They become ONE block of consecutive pool entries appended to X's chain, so
 // point_fix of the reference — older blocks first, scan order inside a block — can be replayed in order by the next fix_divide.
+// A leaf's frame-0 segment holds a handful of points: a GROUP OF 16 LANES per leaf, four leaves per wave (the pass is a chain of
+// dependent memory trips per leaf: what counts is how many leaves are in flight).
 __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int has_var) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, gl = lane & 15, gsh = lane & 48;                 // lane in the group, first lane of the group
   const int ntake = m.cnt[CNT_TAKE];
   const size_t mpz = (size_t)m.max_pts, W = (size_t)P.W, cp = (size_t)m.cap, cf = (size_t)m.cap_fix;
   const int slot = P.mp[0];
   const int *pleaf = m.pleaf + (size_t)slot * mpz;
-  for (int s = blockIdx.x; s < ntake; s += gridDim.x) {
+  for (int s = blockIdx.x * 4 + (lane >> 4); s < ntake; s += gridDim.x * 4) {
     const int X = m.nsl[s], qb = m.wl[s], count = m.wlb[s];      // pool range and chain block were reserved by k_margi_leaf
     if (count == 0) continue;
     int anc = X;
@@ -1303,29 +1317,29 @@ __global__ __launch_bounds__(64) void k_margi_take(MapView m, MapParams P, int h
     if (anc < 0) continue;
     const int start = m.nseg_a[(size_t)slot * cp + anc], end = m.nseg_b[(size_t)slot * cp + anc];
     int off = 0;
-    for (int c0 = start; c0 < end; c0 += 64) {
-      const int i = c0 + lane;
+    for (int c0 = start; c0 < end; c0 += 16) {
+      const int i = c0 + gl;
       const size_t p = (size_t)(i < end ? i : start);          // position in the slot's ordered storage
       const bool mine = i < end && pleaf[p] == X;
-      const unsigned long long mk = __ballot(mine);
+      const unsigned int mk = (unsigned int)((__ballot(mine) >> gsh) & 0xFFFFull);   // the group's 16 bits (its lanes run in step)
       if (mine) {
-        const int o = off + __popcll(mk & ((1ull << lane) - 1ull));
+        const int o = off + __popc(mk & ((1u << gl) - 1u));
         if (o < count) {
           const int q = qb + o;
           const double *sp3 = m.sx + ((size_t)slot * mpz + p) * 3;
           const double bx = sp3[0], by = sp3[1], bz = sp3[2];
           double wx, wy, wz;
           world_point(m.poses, bx, by, bz, wx, wy, wz);                    // pv.pnt = x_buf[0].R * pv.pnt + x_buf[0].p  VM:1551
-          m.fx[q] = wx; m.fx[cf + q] = wy; m.fx[2 * cf + q] = wz;
-          for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + q] = has_var ? m.svar[((size_t)slot * mpz + p) * 9 + k] : 0.0;
+          m.fx[(size_t)q * 3] = wx; m.fx[(size_t)q * 3 + 1] = wy; m.fx[(size_t)q * 3 + 2] = wz;
+          for (int k = 0; k < 9; k++) m.fvar[(size_t)q * 9 + k] = has_var ? m.svar[((size_t)slot * mpz + p) * 9 + k] : 0.0;
           m.fnode[q] = X;
         }
       }
-      off += __popcll(mk);
+      off += __popc(mk);
     }
     // (a leaf at layer < max_layer keeps every raw point, so the segment holds exactly pcrs_local[mp[0]].N entries of X;
     //  should it hold fewer, the rest of the reserved range stays unowned)
-    for (int o = off + lane; o < count; o += 64) m.fnode[qb + o] = -1;
+    for (int o = off + gl; o < count; o += 16) m.fnode[qb + o] = -1;
   }
 }
 // slot mp[0] is emptied (VM:1569-1574: points[mp[0]].clear())
@@ -1705,8 +1719,8 @@ __global__ void k_fix_to_soa(MapView m, int base, int n, const double *pts) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t cf = (size_t)m.cap_fix;
-  for (int k = 0; k < 3; k++) m.fx[(size_t)k * cf + base + p] = pts[(size_t)p * 3 + k];
-  for (int k = 0; k < 9; k++) m.fvar[(size_t)k * cf + base + p] = 0.0;   // push_fix_novar: no covariance
+  for (int k = 0; k < 3; k++) m.fx[(size_t)(base + p) * 3 + k] = pts[(size_t)p * 3 + k];
+  for (int k = 0; k < 9; k++) m.fvar[(size_t)(base + p) * 9 + k] = 0.0;   // push_fix_novar: no covariance
   m.fnode[base + p] = -1;
 }
 
@@ -1785,7 +1799,7 @@ inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
           {(void **)&v.perm, 4, (size_t)W}, {(void **)&v.sx, 24, (size_t)W}, {(void **)&v.svar, 72, (size_t)W}, {(void **)&v.pleaf, 4, (size_t)W}, {(void **)&v.skey_a, 4, 1}, {(void **)&v.skey_b, 4, 1}, {(void **)&v.sval_a, 4, 1}, {(void **)&v.sval_b, 4, 1}, {(void **)&v.wl, 4, 1}, {(void **)&v.wlb, 4, 1}, {(void **)&v.wl4, 16, 1}};
 }
 inline std::vector<DevArr> fix_arrays(MapView &v) {
-  return {{(void **)&v.fx, 8, 3}, {(void **)&v.fvar, 8, 9}, {(void **)&v.fnode, 4, 1}, {(void **)&v.fb_base, 4, 1}, {(void **)&v.fb_len, 4, 1}, {(void **)&v.fb_next, 4, 1}};
+  return {{(void **)&v.fx, 24, 1}, {(void **)&v.fvar, 72, 1}, {(void **)&v.fnode, 4, 1}, {(void **)&v.fb_base, 4, 1}, {(void **)&v.fb_len, 4, 1}, {(void **)&v.fb_next, 4, 1}};
 }
 
 // grow a family of [rows][cap] arrays from oldcap to newcap, keeping the first `used` columns; new space zero-filled
@@ -1849,6 +1863,10 @@ inline int map_ensure(MapStore &s, hipStream_t st, size_t need_nodes, size_t nee
   const int W = s.opt.win_size;
   int rb = map_base(s, st, err);
   if (rb) return rb;
+  // capacity hints of vba_options: taken at the first allocation of each array family
+  if (s.v.cap == 0 && need_nodes > 0 && s.opt.max_map_nodes > need_nodes) need_nodes = s.opt.max_map_nodes;
+  if (s.v.max_pts == 0 && need_pts > 0 && s.opt.max_points_per_scan > need_pts) need_pts = s.opt.max_points_per_scan;
+  if (s.v.cap_fix == 0 && need_fix > 0 && s.opt.max_fix_points > need_fix) need_fix = s.opt.max_fix_points;
   if (need_nodes > (size_t)s.v.cap) {
     size_t nc = s.v.cap ? (size_t)s.v.cap : (size_t)1 << 18;
     while (nc < need_nodes) nc *= 2;
@@ -1995,13 +2013,16 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   }
   if (var) s.have_var = true;
   {  // pose upload through a pinned ring: no implicit synchronisation of a pageable copy
-    if (!s.h_pose_ring) MAPCHK(hipHostMalloc((void **)&s.h_pose_ring, 8 * 12 * sizeof(double), hipHostMallocDefault));
+    if (!s.h_pose_ring) MAPCHK(hipHostMalloc((void **)&s.h_pose_ring, 8 * 32 * sizeof(double), hipHostMallocDefault));   // per entry: pose (12) | rot_var, tsl_var (18)
     const int k = s.pose_next; s.pose_next = (k + 1) & 7;
     if (!s.pose_ev[k]) MAPCHK(hipEventCreateWithFlags(&s.pose_ev[k], hipEventDisableTiming));
     else MAPCHK(hipEventSynchronize(s.pose_ev[k]));
-    std::memcpy(s.h_pose_ring + 12 * k, pose, 12 * sizeof(double));
-    MAPCHK(hipMemcpyAsync(s.v.poses, s.h_pose_ring + 12 * k, 12 * sizeof(double), hipMemcpyHostToDevice, st));
-    if (cov6) MAPCHK(hipMemcpyAsync(s.v.poses + 16, cov6, 18 * sizeof(double), hipMemcpyHostToDevice, st));   // rot_var | tsl_var
+    std::memcpy(s.h_pose_ring + 32 * k, pose, 12 * sizeof(double));
+    MAPCHK(hipMemcpyAsync(s.v.poses, s.h_pose_ring + 32 * k, 12 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (cov6) {                                              // rot_var | tsl_var travel through the same pinned entry
+      std::memcpy(s.h_pose_ring + 32 * k + 12, cov6, 18 * sizeof(double));
+      MAPCHK(hipMemcpyAsync(s.v.poses + 16, s.h_pose_ring + 32 * k + 12, 18 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     MAPCHK(hipEventRecord(s.pose_ev[k], st));
   }
   const MapParams P = map_params(s);
@@ -2044,7 +2065,7 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   MAPCHK(hipGetLastError());
   // no read-back: capacity was reserved for the worst case (n new roots), so this call cannot overflow
   s.ub_nodes += n; s.ub_roots += n; s.ub_used += n; s.cnt_stale = true;
-  if (!is_device_ptr(pnt_body) || cov6) MAPCHK(hipStreamSynchronize(st));   // the caller's host buffers may go away
+  if (!is_device_ptr(pnt_body)) MAPCHK(hipStreamSynchronize(st));   // the caller's host point buffers may go away (pose and covariance went through the pinned ring)
   return VBA_OK;
 }
 
