@@ -37,6 +37,8 @@ def _worker(rank, world, port, out_dir, name="room20k_w4"):
     for i in range(W):
         states[i, 0] = 0.1 * i; states[i, 1:10] = s["R0"][i].ravel(); states[i, 10:13] = s["p0"][i]; states[i, 13:16] = vel[i]; states[i, 22:25] = g
 
+    coll = {}
+
     def run(shard):
         ctx = capi.Context(capi.options_from_workload(wl, stream=torch.cuda.current_stream().cuda_stream))
         if shard:
@@ -46,7 +48,10 @@ def _worker(rank, world, port, out_dir, name="room20k_w4"):
             ctx.cut_voxel(i, s["points"][i], poses[i])
         ctx.recut(W, poses, multi=False)
         nv = ctx.size()
+        c0, d0 = (ctx.collective_calls, ctx.collective_doubles) if shard else (0, 0)
         out = ctx.lidar_ba_damping_iter(poses, max_iter=3, thd_num=2)
+        if shard:      # the exchange of one damping_iter call: one [H | g | r] all-reduce per LM iteration + the voxel count of VM:399
+            coll["calls"] = ctx.collective_calls - c0; coll["doubles"] = ctx.collective_doubles - d0
         # LiDAR-inertial optimiser on the same sharded store: the IMU factors are replicated on every rank, only the
         # lidar [H|g|r] and the residual scalar go through the hook
         ctx.evaluate_only_residual(poses)
@@ -62,15 +67,17 @@ def _worker(rank, world, port, out_dir, name="room20k_w4"):
         htol = 1e-7 if name == "hesai200k_w10" else 1e-8
         def same_trace(a, b):      # accepted rows tightly; a rejected trial step comes out of an ill-conditioned solve (tests/test_gpu_factor.py)
             return a.shape == b.shape and all(np.allclose(ra, rb, rtol=1e-7 if rb[1] < rb[0] else 1e-4, atol=1e-12) for ra, rb in zip(a, b))
-        ok = (int(cnt.item()) == nv_f and np.abs(sharded["poses"] - full["poses"]).max() < 1e-8
+        n6 = 6 * W
+        ok_coll = 0 < coll["calls"] <= 2 * 3 + 4 and coll["doubles"] <= coll["calls"] * (n6 * n6 + n6 + 64)     # nothing per voxel or per point travels
+        ok = (ok_coll and int(cnt.item()) == nv_f and np.abs(sharded["poses"] - full["poses"]).max() < 1e-8
               and same_trace(sharded["trace"], full["trace"])
               and np.abs(sharded["hess"] - full["hess"]).max() < htol * np.abs(full["hess"]).max()
               and np.abs(li_s["states"] - li_f["states"]).max() < 1e-8
               and same_trace(li_s["trace"], li_f["trace"])
               and np.abs(li_s["hess"] - li_f["hess"]).max() < htol * np.abs(li_f["hess"]).max())
         open(os.path.join(out_dir, "ok" if ok else "fail"), "w").write(
-            "voxels %d %d | lidar poses %g | LI states %g FULLROW0 %s trace %s vs %s hess %g" % (
-                int(cnt.item()), nv_f, np.abs(sharded["poses"] - full["poses"]).max(), np.abs(li_s["states"] - li_f["states"]).max(), li_f["trace"][0].tolist(),
+            "collectives %s | voxels %d %d | lidar poses %g | LI states %g FULLROW0 %s trace %s vs %s hess %g" % (
+                coll, int(cnt.item()), nv_f, np.abs(sharded["poses"] - full["poses"]).max(), np.abs(li_s["states"] - li_f["states"]).max(), li_f["trace"][0].tolist(),
                 li_s["trace"].tolist(), li_f["trace"].tolist(), np.abs(li_s["hess"] - li_f["hess"]).max() / np.abs(li_f["hess"]).max()))
     dist.barrier()
     dist.destroy_process_group()
