@@ -110,16 +110,21 @@ def test_full_window_rebuild_parity(capi, oracle, synth, name, with_var):
     assert np.abs(a["poses"] - b["poses"]).max() < 1e-6      # bar: 1e-4 m / 1e-4 rad
 
 
-def test_incremental_local_mapping_parity(capi, oracle, synth):
+@pytest.mark.parametrize("hints", [False, True])
+def test_incremental_local_mapping_parity(capi, oracle, synth, hints):
     """Steady-state loop of thd_odometry_localmapping (voxelslam.cpp:1916-2043): per scan cut_voxel_multi -> multi_recut ->
-    (window full) damping_iter -> multi_margi -> ring rotation, for more scans than the window holds."""
+    (window full) damping_iter -> multi_margi -> ring rotation, for more scans than the window holds.  hints = the map sized once
+    through the capacity hints of vba_options (no re-allocation during the session): same results."""
     import dataclasses
     wl = dataclasses.replace(synth.CONFIGS["room20k_w4"], win_size=4)
     W = wl.win_size
     nscan = 9
     big = dataclasses.replace(wl, win_size=nscan)
     s = synth.make_scans(big)      # nscan scans along the trajectory
-    ctx = capi.Context(_opts(capi, wl))
+    o = _opts(capi, wl)
+    if hints:
+        o.max_points_per_scan, o.max_map_nodes, o.max_fix_points, o.max_voxels = 1 << 15, 1 << 19, 1 << 19, 1 << 14
+    ctx = capi.Context(o)
     om = _omap(oracle, wl)
     of = oracle.Factor(W)
     x_g, x_o = [], []              # window poses on each side
