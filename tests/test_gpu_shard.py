@@ -68,7 +68,7 @@ def _worker(rank, world, port, out_dir, name="room20k_w4"):
         def same_trace(a, b):      # accepted rows tightly; a rejected trial step comes out of an ill-conditioned solve (tests/test_gpu_factor.py)
             return a.shape == b.shape and all(np.allclose(ra, rb, rtol=1e-7 if rb[1] < rb[0] else 1e-4, atol=1e-12) for ra, rb in zip(a, b))
         n6 = 6 * W
-        ok_coll = 0 < coll["calls"] <= 2 * 3 + 4 and coll["doubles"] <= coll["calls"] * (n6 * n6 + n6 + 64)     # nothing per voxel or per point travels
+        ok_coll = 0 < coll["calls"] <= 2 * 3 + 4 and coll["doubles"] <= coll["calls"] * (2 * n6 * n6 + 64 * W)   # the tile-layout image of [H | g | r] per LM iteration (877 doubles at W = 4) + one count: nothing per voxel or per point travels
         ok = (ok_coll and int(cnt.item()) == nv_f and np.abs(sharded["poses"] - full["poses"]).max() < 1e-8
               and same_trace(sharded["trace"], full["trace"])
               and np.abs(sharded["hess"] - full["hess"]).max() < htol * np.abs(full["hess"]).max()
