@@ -405,34 +405,54 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
 }
 
 // only_residual's IMU part at the trial states (VM:605-607 / 851-854) + the accept / reject bookkeeping of VM:675-706.
-__global__ __launch_bounds__(64) void k_li_update(LmDev *s, LiDev *li, double *__restrict__ imu, const double *__restrict__ r2_dev, int nb) {
+// One workgroup of 256 threads: lane f of wave 0 evaluates factor f's residual (a serial chain), thread (f, r) then forms row r of
+// cov^-1 r_f (the 225 loads per factor that one lane used to issue alone), lane f closes r^T (cov^-1 r) in the reference's order;
+// the bookkeeping stays on wave 0.  Everything the bookkeeping reads is requested before the residual chain starts.
+constexpr int LI_UPD_NT = 256;
+__global__ __launch_bounds__(LI_UPD_NT) void k_li_update(LmDev *s, LiDev *li, double *__restrict__ imu, const double *__restrict__ r2_dev, int nb) {
+  __shared__ double rr_s[LI_MAX_W][15], a_s[LI_MAX_W][15];
   if (s->stop) return;
-  const int lane = threadIdx.x, W = li->W, F = li->F;
-  double qi = 0.0;
-  if (lane < F) {
-    vbh::State s1, s2;
-    li_state(s->xt + 12 * lane, li->ext + 12 * lane, li->tstamp[lane], s1);
-    li_state(s->xt + 12 * (lane + 1), li->ext + 12 * (lane + 1), li->tstamp[lane + 1], s2);
-    double rr[15];
-    const double *m = imu + 304 * (size_t)lane;
-    vbh::imu_residual_jacobian(*reinterpret_cast<const vbh::ImuPre *>(m), s1, s2, li->gravity != 0, rr, nullptr, li->nb);
-    for (int r = 0; r < 15; r++) { double a = 0; for (int k = 0; k < 15; k++) a += m[79 + 15 * r + k] * rr[k]; qi += rr[r] * a; }
+  const int tid = threadIdx.x, lane = tid & 63, W = li->W, F = li->F;
+  // (hoisted: one memory trip together with the states below instead of one more after the residual)
+  const double r1 = s->r1, q1 = s->q1, u0 = s->u, v0 = s->v;
+  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter, spec_n = s->spec_n, spec_nx = s->spec_i + 1;
+  double r2acc = 0.0;
+  if (tid < 64) {
+    if (nb > 0) for (int b = lane; b < nb; b += 64) r2acc += r2_dev[b];
+    else if (lane == 0) r2acc = *r2_dev;
   }
+  if (tid < F) {
+    vbh::State s1, s2;
+    li_state(s->xt + 12 * tid, li->ext + 12 * tid, li->tstamp[tid], s1);
+    li_state(s->xt + 12 * (tid + 1), li->ext + 12 * (tid + 1), li->tstamp[tid + 1], s2);
+    double rr[15];
+    vbh::imu_residual_jacobian(*reinterpret_cast<const vbh::ImuPre *>(imu + 304 * (size_t)tid), s1, s2, li->gravity != 0, rr, nullptr, li->nb);
+    for (int k = 0; k < 15; k++) rr_s[tid][k] = rr[k];
+  }
+  __syncthreads();
+  if (tid < 15 * F) {
+    const int f = tid / 15, r = tid - 15 * f;
+    const double *m = imu + 304 * (size_t)f + 79 + 15 * r;
+    double a = 0;
+    for (int k = 0; k < 15; k++) a += m[k] * rr_s[f][k];
+    a_s[f][r] = a;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  double qi = 0.0;
+  if (lane < F) for (int r = 0; r < 15; r++) qi += rr_s[lane][r] * a_s[lane][r];
   // (sum over factors in ascending order, like the reference's loop)
   double rimu = 0.0;
   for (int f = 0; f < F; f++) rimu += readlane_f64(qi, f);
   double r2;
   if (nb > 0) {
-    double acc = 0.0;
-    for (int b = lane; b < nb; b += 64) acc += r2_dev[b];
+    double acc = r2acc;
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
     r2 = acc;
   } else {
-    r2 = *r2_dev;
+    r2 = readlane_f64(r2acc, 0);
   }
   r2 += rimu * (li->imu_coef * 0.5);
-  const double r1 = s->r1, q1 = s->q1, u0 = s->u, v0 = s->v;
-  const int ntr = s->n_trace, mtr = s->max_trace, it = s->iter, spec_n = s->spec_n, spec_nx = s->spec_i + 1;
   const bool have_spec = spec_nx < spec_n;        // a solved candidate for the damping a rejection leads to (k_li_solve)
   const int sc = have_spec ? spec_nx : 0;
   double q = r1 - r2, u = u0, v = v0;

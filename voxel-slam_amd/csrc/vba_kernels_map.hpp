@@ -1677,33 +1677,44 @@ __global__ void k_var_init(int n, const double *__restrict__ pin, double *__rest
 
 // pvec_update (voxelslam.hpp:242-265) fused into the staging of a scan: var_world = R var R^T + phat rot_var phat^T + tsl_var
 // (pw = R p + t is recomputed by the insert kernels).  cov6 = [rot_var(9) | tsl_var(9)].
-__global__ void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, const double *pts, const double *var, const double *pose, const double *cov6) {
+__global__ __launch_bounds__(256) void k_scan_to_soa_pvec_update(MapView m, int W, int slot, int n, const double *pts, const double *var, const double *pose, const double *cov6) {
 #pragma clang fp contract(off)      // the reference's operation order, separately rounded (cov_add sums these values in order: see ord_terms)
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // A thread owns a point, but 72-byte records read with one 8-byte load per lane touch 36 lines per instruction: the workgroup moves
+  // its 256 records through LDS with consecutive lanes on consecutive doubles (rows of 9 / 3 doubles: conflict-free for the owner).
+  __shared__ double sv[256 * 9], sp[256 * 3];
+  const int tid = threadIdx.x, base = blockIdx.x * 256, p = base + tid;
   if (p == 0) { m.cnt[CNT_NEWSLOTS] = 0; m.cnt[CNT_TOUCH] = 0; m.cnt[CNT_WL] = 0; m.cnt[CNT_WLB] = 0; m.cnt[CNT_CURSOR] = 0; }   // the insert's counters (no kernels of their own)
-  if (p >= n) return;
+  const int cnt = n - base < 256 ? n - base : 256;
+  for (int i = tid; i < cnt * 9; i += 256) sv[i] = var[(size_t)base * 9 + i];
+  for (int i = tid; i < cnt * 3; i += 256) sp[i] = pts[(size_t)base * 3 + i];
+  __syncthreads();
   const size_t mpz = (size_t)m.max_pts;
-  const double bx = pts[(size_t)p * 3], by = pts[(size_t)p * 3 + 1], bz = pts[(size_t)p * 3 + 2];
-  { double *pp = m.px + ((size_t)slot * mpz + p) * 3; pp[0] = bx; pp[1] = by; pp[2] = bz; }
-  const double *R = pose;
-  double v[9], RV[9], PR[9];
+  if (tid < cnt) {
+    const double bx = sp[tid * 3], by = sp[tid * 3 + 1], bz = sp[tid * 3 + 2];
+    const double *R = pose;
+    double v[9], RV[9], PR[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) v[k] = var[(size_t)p * 9 + k];
+    for (int k = 0; k < 9; k++) v[k] = sv[tid * 9 + k];
 #pragma unroll
-  for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) RV[3 * r + c] = (R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c]) + R[3 * r + 2] * v[6 + c];
-  const double ph[9] = {0, -bz, by, bz, 0, -bx, -by, bx, 0};
+      for (int c = 0; c < 3; c++) RV[3 * r + c] = (R[3 * r] * v[c] + R[3 * r + 1] * v[3 + c]) + R[3 * r + 2] * v[6 + c];
+    const double ph[9] = {0, -bz, by, bz, 0, -bx, -by, bx, 0};
 #pragma unroll
-  for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) PR[3 * r + c] = (ph[3 * r] * cov6[c] + ph[3 * r + 1] * cov6[3 + c]) + ph[3 * r + 2] * cov6[6 + c];
+      for (int c = 0; c < 3; c++) PR[3 * r + c] = (ph[3 * r] * cov6[c] + ph[3 * r + 1] * cov6[3 + c]) + ph[3 * r + 2] * cov6[6 + c];
 #pragma unroll
-  for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-      m.pvar[((size_t)slot * mpz + p) * 9 + 3 * r + c] = (((RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1]) + RV[3 * r + 2] * R[3 * c + 2]) +
-                                                            ((PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1]) + PR[3 * r + 2] * ph[3 * c + 2])) + cov6[9 + 3 * r + c];
+      for (int c = 0; c < 3; c++)
+        sv[tid * 9 + 3 * r + c] = (((RV[3 * r] * R[3 * c] + RV[3 * r + 1] * R[3 * c + 1]) + RV[3 * r + 2] * R[3 * c + 2]) +
+                                   ((PR[3 * r] * ph[3 * c] + PR[3 * r + 1] * ph[3 * c + 1]) + PR[3 * r + 2] * ph[3 * c + 2])) + cov6[9 + 3 * r + c];
+  }
+  __syncthreads();
+  double *ov = m.pvar + ((size_t)slot * mpz + base) * 9, *op = m.px + ((size_t)slot * mpz + base) * 3;
+  for (int i = tid; i < cnt * 9; i += 256) ov[i] = sv[i];
+  for (int i = tid; i < cnt * 3; i += 256) op[i] = sp[i];
 }
 
 // host layout [n][3] / [n][9] -> the scan slot's staging arrays (same AoS layout)

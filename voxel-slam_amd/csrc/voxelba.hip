@@ -1079,18 +1079,18 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
       st = hessian_pass(c, xt_dev, run_res, 0, V);
       if (st) { c->lm.active = false; return st; }
       c->lm.have_hess = true;
-      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_out + (nout_tl(W) - 1), 0);
+      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(LI_UPD_NT), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_out + (nout_tl(W) - 1), 0);
     } else if (V == 0) {
       st = residual_pass(c, xt_dev, run_res, 0, V, c->d_scal);
       if (st) { c->lm.active = false; return st; }
-      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_scal, 0);
+      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(LI_UPD_NT), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_scal, 0);
     } else {
       const int nbk = residual_nb(c, V);
       TimedSpan s2{};
       span_begin(c, "residual", s2);
       launch_residual(c, xt_dev, run_res, 0, V);
       span_end(c, "residual", s2);
-      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(64), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_partial, nbk);
+      hipLaunchKernelGGL(k_li_update, dim3(1), dim3(LI_UPD_NT), 0, c->stream, c->d_lm, c->d_li, c->d_imu, c->d_partial, nbk);
     }
     HIPCHK(c, hipGetLastError());
   }
