@@ -319,23 +319,19 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   }
   __syncthreads();
   if ((dbg & 16) && tid == 0) s->stamps[52] = clock64();
-  if (tid < n) ord[tid] = 0;                       // rank of row i = #{j : |d_j| > |d_i| or (equal and j < i)}, 3 threads per row
-  __syncthreads();
-  {
-    const int i = tid % NMAX, part = tid / NMAX, parts = NT / NMAX;
-    if (i < n && part < parts) {
-      const double me = dsh[i];
-      const int j0 = part * ((n + parts - 1) / parts), j1 = (j0 + (n + parts - 1) / parts < n) ? j0 + (n + parts - 1) / parts : n;
-      int cnt = 0;
-#pragma unroll 8
-      for (int j = j0; j < j1; j++) { const double o = dsh[j]; cnt += (o > me || (o == me && j < i)) ? 1 : 0; }
-      atomicAdd(&ord[i], cnt);
-    }
+  // Elimination order = the STRUCTURE of the system ("eliminate the 9W velocity / bias block first"): the v, bg, ba
+  // of frame 0, 1, ... W-1 (block-tridiagonal through the IMU factors, VM:551-567), then the 6W pose scalars (dense through the
+  // lidar part), then gravity.  Column c of frame i's block then reaches only the rest of its block, frame i+1's block, the poses
+  // of frames 0..i+1 (i-1, i, i+1 directly, the older ones as fill of the chain), gravity and the right-hand side: the trailing
+  // update of most tiles is skipped (li_live_rows).  The reference's Eigen LDLT pivots by the largest remaining diagonal (VM:659);
+  // the system is symmetric positive definite (damped), for which every order is backward stable — the results move in the last
+  // digits, inside the bars of the LI parity tests (same bars as before).
+  if (tid < n) {
+    int o = tid;
+    if (tid < 9 * W) { const int i = tid / 9; o = 15 * i + 6 + (tid - 9 * i); }
+    else if (tid < 15 * W) { const int q = tid - 9 * W, i = q / 6; o = 15 * i + (q - 6 * i); }
+    ord[tid] = o;
   }
-  __syncthreads();
-  int my_rank = (tid < n) ? ord[tid] : 0;
-  __syncthreads();
-  if (tid < n) ord[my_rank] = tid;
   __syncthreads();
   // element (i, j) of the padded system: P (H + u D) P^T lower triangle, row n = -g, identity on the padding
   auto elem = [&](int i, int j) -> double {
@@ -351,7 +347,18 @@ __global__ __launch_bounds__(NT) void k_li_solve(LmDev *s, LiDev *li, const doub
   };
   long long *stamps = ((dbg & 16) != 0) ? s->stamps : nullptr;
   if (stamps && tid == 0) stamps[1] = clock64();
-  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem, stamps);
+  auto live = [&](int kb) -> unsigned {               // 16-row blocks that can hold a non-zero of L in the columns [8 kb, 8 kb + 8)
+    const int c0 = 8 * kb, c1 = c0 + 7;
+    auto span = [](int a, int b) -> unsigned { return (a < b) ? ((2u << ((b - 1) >> 4)) - 1u) & ~((1u << (a >> 4)) - 1u) : 0u; };   // rows [a, b)
+    if (c0 >= 9 * W) return span(c0, NP);
+    const int ihi = (c1 < 9 * W ? c1 : 9 * W - 1) / 9;                                   // last frame the panel touches
+    unsigned m = span(c0, (9 * (ihi + 2) < 9 * W) ? 9 * (ihi + 2) : 9 * W);            // its own blocks and the next frame's
+    m |= span(9 * W, (6 * (ihi + 2) < 6 * W) ? 9 * W + 6 * (ihi + 2) : 15 * W);        // poses of frames 0 .. ihi + 1
+    m |= span(15 * W, n + 1);                                                            // gravity, right-hand side row
+    if (c1 >= 9 * W) m |= span(9 * W, NP);                                               // a panel that straddles into the pose block
+    return m;
+  };
+  ldlt_mfma<NP, NT>(Lst, Tp, P, n, elem, stamps, live);
   if (stamps && tid == 0) stamps[3] = clock64();
   if (tid < n) xs[tid] = Lst[LC::lat(n, tid)];                                  // z = D^-1 L^-1 P (-g)
   __syncthreads();

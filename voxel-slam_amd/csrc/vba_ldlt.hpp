@@ -36,8 +36,12 @@ struct LdltCfg {
   __device__ static __forceinline__ int lat(int j, int i) { return lst_off(i >> 3) + (j - (i & ~7)) * LS + (i & 7); }   // L[j][i], j > i
 };
 
-template <int NP, int NT, typename F>
-__device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__restrict__ Tp, double *__restrict__ P, int rhs_row, F elem, long long *stamps = nullptr) {
+// `live(kb)` = bit b set when rows [16 b, 16 b + 16) can hold a non-zero of L in the columns of panel kb (a SUPERSET of the
+// structure is fine): the rank-8 update of a tile whose row block or column block is dead for the panel is skipped.  A dense
+// system passes LdltDense.
+struct LdltDense { __device__ __forceinline__ unsigned operator()(int) const { return ~0u; } };
+template <int NP, int NT, typename F, typename LV = LdltDense>
+__device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__restrict__ Tp, double *__restrict__ P, int rhs_row, F elem, long long *stamps = nullptr, LV live = LV()) {
   using C = LdltCfg<NP>;
   constexpr int NW = NT / 64, TPW = (C::NTILES + NW - 1) / NW, LS = C::LS;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, lr = l >> 4, lc = l & 15;
@@ -114,11 +118,14 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
     const int kn = k0 + 8;
     if (kn >= NP) break;
     const int tjn = kn >> 4, cb0 = kn & 15;
+    const unsigned lm = (unsigned)__builtin_amdgcn_readfirstlane((int)live(kb));
     // operands of every live tile first (unconditional loads on clamped rows: they overlap), then the MFMAs
     double la0[TPW], la1[TPW], tb0[TPW], tb1[TPW];
+    bool actv[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; u++) {
-      const bool act = (w + NW * u < C::NTILES) && (ttj[u] >= tjn);
+      const bool act = (w + NW * u < C::NTILES) && (ttj[u] >= tjn) && ((lm >> tti[u]) & 1u) && ((lm >> ttj[u]) & 1u);    // wave-uniform
+      actv[u] = act;
       const double *la = Lk + (act ? (16 * tti[u] + lc - k0) : 0) * LS + lr, *tb = Tp + (act ? (16 * ttj[u] + lc) : k0) * LS + lr;
       la0[u] = la[0]; la1[u] = la[4]; tb0[u] = tb[0]; tb1[u] = tb[4];
     }
@@ -126,15 +133,14 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
     //  the instruction's dependent latency, ~115 cycles, instead of its 64-cycle issue rate)
 #pragma unroll
     for (int u = 0; u < TPW; u++)
-      if ((w + NW * u < C::NTILES) && (ttj[u] >= tjn)) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la0[u], tb0[u], acc[u], 0, 0, 0);
+      if (actv[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la0[u], tb0[u], acc[u], 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < TPW; u++) {
-      if ((w + NW * u < C::NTILES) && (ttj[u] >= tjn)) {    // wave-uniform
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la1[u], tb1[u], acc[u], 0, 0, 0);
-        if (ttj[u] == tjn && lc >= cb0 && lc < cb0 + 8)
+      if (actv[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la1[u], tb1[u], acc[u], 0, 0, 0);
+      // the next panel's columns are published by their tile column whether or not this panel touched the tile
+      if ((w + NW * u < C::NTILES) && ttj[u] == tjn && lc >= cb0 && lc < cb0 + 8)
 #pragma unroll
-          for (int r = 0; r < 4; r++) P[(16 * tti[u] + lr + 4 * r) * 8 + (lc - cb0)] = acc[u][r];
-      }
+        for (int r = 0; r < 4; r++) P[(16 * tti[u] + lr + 4 * r) * 8 + (lc - cb0)] = acc[u][r];
     }
   }
   __syncthreads();
