@@ -1828,9 +1828,14 @@ inline int grow_arrays(std::vector<DevArr> arrs, size_t oldcap, size_t newcap, s
   return VBA_OK;
 }
 
+// device -> pinned host memory by a kernel: a D2H copy queued behind in-flight kernels completes much later (measured), and draining
+// the stream first costs a second host round trip; a 64-thread kernel that stores through the host mapping needs one.
+__global__ void k_words_to_host(const int *__restrict__ src, int *__restrict__ dst, int n) {
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x) dst[i] = src[i];
+}
 inline int map_read_counters(MapStore &s, hipStream_t st, std::string &err) {
-  MAPCHK(hipStreamSynchronize(st));     // drain first: a D2H copy queued behind in-flight kernels completes much later (measured)
-  MAPCHK(hipMemcpyAsync(s.h_cnt, s.v.cnt, CNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_words_to_host, dim3(1), dim3(64), 0, st, s.v.cnt, s.h_cnt, (int)CNT_N);
+  MAPCHK(hipGetLastError());
   MAPCHK(hipStreamSynchronize(st));
   s.ub_nodes = s.h_cnt[CNT_NODES]; s.ub_roots = s.h_cnt[CNT_ROOTS]; s.ub_used = s.h_cnt[CNT_USED]; s.cnt_stale = false;
   return VBA_OK;

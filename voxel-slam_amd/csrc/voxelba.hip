@@ -901,16 +901,18 @@ int vba_lm_end(vba_ctx *c, double *poses, double *hess, double *resis2) {
     c->lm.pending_update = false;
   }
   if (!poses && !hess && !resis2) { c->lm.active = false; return VBA_OK; }    // nothing requested: no synchronisation
-  HIPCHK(c, hipStreamSynchronize(c->stream));      // drain first (D2H copies queued behind in-flight kernels complete much later, see li_ba_device)
-  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, c->stream));
+  // One host round trip: the LM state (and *hess) reach the pinned mirrors through kernels that store via the host mapping — a D2H
+  // copy queued behind in-flight kernels completes much later (see li_ba_device), and draining the stream first is a second trip.
+  hipLaunchKernelGGL(k_words_to_host, dim3(4), dim3(256), 0, c->stream, (const int *)c->d_lm, (int *)c->h_lm, (int)(sizeof(LmDev) / 4));
   if (hess) {
     int st = ensure_pin(c, 65536 + (size_t)n * n + 1024);
     if (st) return st;
     const double *src = c->collective() ? c->d_raw : c->d_out;    // *hess = Hess before gauge fixing (VM:446)
     st = tiles_to_full(c, src);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + 32768, c->d_full, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(k_words_to_host, dim3(16), dim3(256), 0, c->stream, (const int *)c->d_full, (int *)(c->h_pin + 32768), n * n * 2);
   }
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const LmDev *h = c->h_lm;
   if (poses) std::memcpy(poses, h->x, (size_t)W * 12 * sizeof(double));
@@ -1106,12 +1108,6 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
                o_lm = o_lid + (size_t)n6 * n6, o_end = o_lm + sizeof(LmDev) / 8;
   st = ensure_pin(c, o_end + 64);
   if (st) return st;
-  if (o_end + 64 > c->lipack_doubles) {
-    if (c->d_lipack) hipFree(c->d_lipack);
-    c->d_lipack = nullptr; c->lipack_doubles = 0;
-    HIPCHK(c, hipMalloc((void **)&c->d_lipack, (o_end + 64) * sizeof(double)));
-    c->lipack_doubles = o_end + 64;
-  }
   PackSegs segs{};
   segs.n = 3;
   segs.src[0] = (const double *)c->d_li; segs.off[0] = o_li; segs.len[0] = sizeof(LiDev) / 8;
@@ -1124,9 +1120,9 @@ static int li_ba_device(vba_ctx *c, double *states, double *imus, int gravity, i
     segs.src[3] = c->d_full; segs.off[3] = o_lid; segs.len[3] = (size_t)n6 * n6;
     segs.src[4] = c->d_himu; segs.off[4] = o_hb; segs.len[4] = (size_t)li_hb_size(W, gravity);
   }
-  hipLaunchKernelGGL(k_pack_segments, dim3(64, segs.n), dim3(256), 0, c->stream, segs, c->d_lipack);
+  // (the gather kernel stores straight through the host mapping of the pinned block: no copy command behind it)
+  hipLaunchKernelGGL(k_pack_segments, dim3(64, segs.n), dim3(256), 0, c->stream, segs, c->h_pin);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_lipack, o_end * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(c->h_lm, c->h_pin + o_lm, sizeof(LmDev));
   std::memcpy(&h, c->h_pin + o_li, sizeof(LiDev));
