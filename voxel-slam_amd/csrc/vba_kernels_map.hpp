@@ -2029,16 +2029,14 @@ inline int map_cut_voxel(MapStore &s, hipStream_t st, int win_count, int n, cons
   }
   if (var) s.have_var = true;
   {  // pose upload through a pinned ring: no implicit synchronisation of a pageable copy
-    if (!s.h_pose_ring) MAPCHK(hipHostMalloc((void **)&s.h_pose_ring, 8 * 32 * sizeof(double), hipHostMallocDefault));   // per entry: pose (12) | rot_var, tsl_var (18)
+    if (!s.h_pose_ring) MAPCHK(hipHostMalloc((void **)&s.h_pose_ring, 8 * 40 * sizeof(double), hipHostMallocDefault));
     const int k = s.pose_next; s.pose_next = (k + 1) & 7;
     if (!s.pose_ev[k]) MAPCHK(hipEventCreateWithFlags(&s.pose_ev[k], hipEventDisableTiming));
     else MAPCHK(hipEventSynchronize(s.pose_ev[k]));
-    std::memcpy(s.h_pose_ring + 32 * k, pose, 12 * sizeof(double));
-    MAPCHK(hipMemcpyAsync(s.v.poses, s.h_pose_ring + 32 * k, 12 * sizeof(double), hipMemcpyHostToDevice, st));
-    if (cov6) {                                              // rot_var | tsl_var travel through the same pinned entry
-      std::memcpy(s.h_pose_ring + 32 * k + 12, cov6, 18 * sizeof(double));
-      MAPCHK(hipMemcpyAsync(s.v.poses + 16, s.h_pose_ring + 32 * k + 12, 18 * sizeof(double), hipMemcpyHostToDevice, st));
-    }
+    // entry = the device image poses[0 .. 34): pose (12) | 4 unused | rot_var, tsl_var (18) — one copy command
+    std::memcpy(s.h_pose_ring + 40 * k, pose, 12 * sizeof(double));
+    if (cov6) std::memcpy(s.h_pose_ring + 40 * k + 16, cov6, 18 * sizeof(double));
+    MAPCHK(hipMemcpyAsync(s.v.poses, s.h_pose_ring + 40 * k, (cov6 ? 34 : 12) * sizeof(double), hipMemcpyHostToDevice, st));
     MAPCHK(hipEventRecord(s.pose_ev[k], st));
   }
   const MapParams P = map_params(s);
