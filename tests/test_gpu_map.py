@@ -194,6 +194,36 @@ def test_fixed_point_insertion_parity(capi, oracle, synth):
     assert ctx.size() == of.size()
 
 
+def test_recut_replays_long_fixed_point_chains(capi, oracle, synth):
+    """fix_divide (voxel_map.hpp:1270-1299) over a leaf whose point_fix arrived in MANY blocks (150 keyframe loads of 4 points into one
+    voxel: more blocks than one batch of the block list holds, more entries than one group of 256) and subdivide over more window
+    points than one group: the children's sums must still be the reference's chains, bit for bit, down two levels."""
+    wl = synth.CONFIGS["room20k_w4"]
+    W = wl.win_size
+    rng = np.random.default_rng(7)
+    vs = wl.voxel_size
+    c0 = np.array([3.0, 2.0, 1.0]) * vs + 0.5 * vs                       # centre of one voxel
+    ctx = capi.Context(_opts(capi, wl))
+    om = _omap(oracle, wl)
+    for k in range(150):
+        pts = c0 + rng.uniform(-0.45, 0.45, (4, 3)) * vs
+        ctx.cut_voxel_fix(pts, jour=float(k)); om.cut_voxel_fix(pts, jour=float(k))
+    poses = np.tile(np.concatenate([np.eye(3).ravel(), np.zeros(3)]), (W, 1))
+    for i in range(W):
+        pts = c0 + rng.uniform(-0.45, 0.45, (120, 3)) * vs               # a blob, not a plane: the root splits, most children again
+        far = np.array([40.0, 40.0, 5.0]) + rng.uniform(0, 1, (30, 3))   # a second voxel, so that the map is not a single root
+        sc = np.ascontiguousarray(np.concatenate([pts, far]))
+        ctx.cut_voxel(i, sc, poses[i]); om.cut_voxel(i, sc, poses[i])
+    of = oracle.Factor(W)
+    ctx.recut(W, poses, multi=False); om.recut(W, poses, of, multi=False)
+    gd, od = ctx.dump_leaves(), om.dump_leaves()
+    _compare_leaves(gd, od)
+    assert len(_leaf_table(od)) > 8 and ctx.size() == of.size()
+    # the children got both kinds of points
+    fixed_in_children = sum(1 for r in _leaf_table(od).values() if r[6] > 0 and r[5] > r[6])
+    assert fixed_in_children > 4
+
+
 def test_scan_dropped_when_fewer_voxels_than_threads(capi, oracle):
     """cut_voxel_multi silently drops a scan that touches fewer voxels than thread_num (voxel_map.hpp:2044-2045)."""
     o = capi.default_options(); o.win_size = 4; o.voxel_size = 1.0; o.thread_num = 5

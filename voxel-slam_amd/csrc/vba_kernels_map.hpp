@@ -166,6 +166,8 @@ __device__ __forceinline__ double &nlc_at(const MapView &m, size_t W, int k, int
 __device__ __forceinline__ double &nadd_at(const MapView &m, int k, size_t id) { return m.nadd[id * 10 + k]; }
 __device__ __forceinline__ double &nfix_at(const MapView &m, int k, size_t id) { return m.nfix[id * 10 + k]; }
 __device__ __forceinline__ double &ncov_at(const MapView &m, int k, size_t id) { return m.ncov[id * 45 + k]; }
+__device__ __forceinline__ double &neval_at(const MapView &m, int k, size_t id) { return m.neval[id * 3 + k]; }   // eigen-pairs of the node's plane fit: node-major too
+__device__ __forceinline__ double &nevec_at(const MapView &m, int k, size_t id) { return m.nevec[id * 9 + k]; }   // (the extraction reads them per factor)
 // where scalar k of a leaf lives: [0..8] nlc (slot cluster), [9..17] nadd (pcr_add), [18..62] ncov (cov_add)
 __device__ __forceinline__ double *ord_target(const MapView &m, int W, int slot, int k, int leaf) {
   return k < 9 ? &nlc_at(m, (size_t)W, k, slot, leaf) : k < 18 ? &nadd_at(m, k - 9, leaf) : &ncov_at(m, k - 18, leaf);
@@ -717,9 +719,9 @@ __global__ __launch_bounds__(256) void k_recut_leaf(MapView m, MapParams P, int 
     double w0, w1, w2, V[9];
     eig3_sym_dev(nadd_at(m, 0, id) / N - b0 * b0, nadd_at(m, 1, id) / N - b1 * b0, nadd_at(m, 2, id) / N - b2 * b0,
                  nadd_at(m, 3, id) / N - b1 * b1, nadd_at(m, 4, id) / N - b2 * b1, nadd_at(m, 5, id) / N - b2 * b2, w0, w1, w2, V);
-    m.neval[id] = w0; m.neval[cp + id] = w1; m.neval[2 * cp + id] = w2;
+    neval_at(m, 0, id) = w0; neval_at(m, 1, id) = w1; neval_at(m, 2, id) = w2;
 #pragma unroll
-    for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = V[k];
+    for (int k = 0; k < 9; k++) nevec_at(m, k, id) = V[k];
     const bool plane = (w0 < P.min_eigen_value) && ((w0 / w2) < P.plane_thre[L]);   // plane_judge VM:1194
     m.f_plane[id] = plane ? 1 : 0;
     if (plane || L >= P.max_layer) break;
@@ -842,6 +844,7 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
   for (int s = blockIdx.x; s < nsplit; s += gridDim.x) {
     const int X = m.nsl[s];
     const int base = m.nchild[X];
+    const double ctr[3] = {m.ncenter[X], m.ncenter[cp + X], m.ncenter[2 * cp + X]};     // (requested with the leaf's other fields)
     for (int i = tid; i < 8 * 64; i += GC) A[i] = 0.0;
     if (tid < 8) { nw[tid] = 0; nf[tid] = 0; }
     __syncthreads();
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
 #pragma unroll
                 for (int k = 0; k < 9; k++) var[k] = m.fvar[(size_t)q * 9 + k];
               }
-              child = octant_of(m, X, x, y, z);
+              child = 4 * (x > ctr[0] ? 1 : 0) + 2 * (y > ctr[1] ? 1 : 0) + (z > ctr[2] ? 1 : 0);
               ord_terms<HAS_VAR>(t, 0.0, 0.0, 0.0, x, y, z, var);     // pcr_fix.push(pnt); pcr_add.push(pnt); cov_add += Bf_var(pv, pnt)
               m.fnode[q] = (child_layer < P.max_layer) ? base + child : -1;          // VM:1152-1153
             }
@@ -927,17 +930,20 @@ __global__ __launch_bounds__(256) void k_recut_push(MapView m, MapParams P, int 
         while (tpos >= foff[f + 1]) f++;
         const int slot = P.mp[f];
         const size_t p = (size_t)(fs[f] + (tpos - foff[f]));      // position in the slot's ordered storage: no indirection
-        if (m.pleaf[(size_t)slot * mpz + p] == X) {
-          const double *sp3 = m.sx + ((size_t)slot * mpz + p) * 3;
-          const double bx = sp3[0], by = sp3[1], bz = sp3[2];
-          double var[9];
-          if (HAS_VAR) {
+        // the point is requested together with its owner tag (one memory trip instead of two: this pass is a chain of trips per leaf,
+        // the bytes of the candidates that turn out to be a sibling's do not matter)
+        const int owner = m.pleaf[(size_t)slot * mpz + p];
+        const double *sp3 = m.sx + ((size_t)slot * mpz + p) * 3;
+        const double bx = sp3[0], by = sp3[1], bz = sp3[2];
+        double var[9];
+        if (HAS_VAR) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) var[k] = m.svar[((size_t)slot * mpz + p) * 9 + k];
-          }
+          for (int k = 0; k < 9; k++) var[k] = m.svar[((size_t)slot * mpz + p) * 9 + k];
+        }
+        if (owner == X) {
           double x, y, z;
           world_point(m.poses + 12 * f, bx, by, bz, x, y, z);
-          child = octant_of(m, X, x, y, z);
+          child = 4 * (x > ctr[0] ? 1 : 0) + 2 * (y > ctr[1] ? 1 : 0) + (z > ctr[2] ? 1 : 0);   // octant_of(X): VM:1214-1219
           ord_terms<HAS_VAR>(t, bx, by, bz, x, y, z, var);
           m.pleaf[(size_t)slot * mpz + p] = base + child;
 #ifdef VBA_DIAG
@@ -980,7 +986,7 @@ __global__ __launch_bounds__(256) void k_extract_count(MapView m, MapParams P, i
   if (take && !in_scope(m, P, id, multi)) take = false;
   if (take && !(m.f_exist[id] && m.f_plane[id] && m.f_sw[id])) take = false;
   const size_t cp = (size_t)m.cap;
-  if (take && m.neval[id] / m.neval[cp + id] > 0.12) take = false;   // VM:1615
+  if (take && neval_at(m, 0, id) / neval_at(m, 1, id) > 0.12) take = false;   // VM:1615
   const unsigned long long mask = __ballot(take);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wbase[wave] = __popcll(mask);
@@ -1085,8 +1091,8 @@ __global__ __launch_bounds__(256) void k_extract_write(MapView m, MapParams P, F
       if (r < 10) v = nfix_at(m, r, id);
       else if (r < 20) v = nadd_at(m, r - 10, id);
       else if (r == 20) v = 1.0;                              // coe  VM:1619
-      else if (r < 24) v = m.neval[(size_t)(r - 21) * cp + id];
-      else v = m.nevec[(size_t)(r - 24) * cp + id];
+      else if (r < 24) v = neval_at(m, r - 21, id);
+      else v = nevec_at(m, r - 24, id);
     }
     xw_buf[row * (XW_F + 1) + j] = v;
   }
@@ -1233,8 +1239,8 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
   const size_t cp = (size_t)m.cap, W = (size_t)P.W, vs = (size_t)f.vs;
   double add[10], fix[10], pw0[10], ev[3], U[9], lc[10];
   for (int k = 0; k < 10; k++) fix[k] = nfix_at(m, k, id);
-  for (int k = 0; k < 3; k++) ev[k] = m.neval[(size_t)k * cp + id];
-  for (int k = 0; k < 9; k++) U[k] = m.nevec[(size_t)k * cp + id];
+  for (int k = 0; k < 3; k++) ev[k] = neval_at(m, k, id);
+  for (int k = 0; k < 9; k++) U[k] = nevec_at(m, k, id);
   for (int k = 0; k < 10; k++) pw0[k] = 0.0;
   const int opt = m.nopt[id];
   if (opt >= nfac) { atomicMax(&m.cnt[CNT_OVERFLOW], 2); return 0; }     // VM:1488-1492 "Error: opt_state"
@@ -1275,8 +1281,8 @@ __device__ __forceinline__ int margi_leaf_body(const MapView &m, const MapParams
                    ev[0], ev[1], ev[2], U);
     }
   }
-  for (int k = 0; k < 3; k++) m.neval[(size_t)k * cp + id] = ev[k];
-  for (int k = 0; k < 9; k++) m.nevec[(size_t)k * cp + id] = U[k];
+  for (int k = 0; k < 3; k++) neval_at(m, k, id) = ev[k];
+  for (int k = 0; k < 9; k++) nevec_at(m, k, id) = U[k];
   if (fix[9] < P.max_points && m.f_plane[id]) {             // VM:1532-1538
     const int last = m.nlast[id];
     if ((int)add[9] - last >= 5 || last <= 10) { plane_update_dev(m, id, add, ev, U); m.nlast[id] = (int)add[9]; }
@@ -1449,9 +1455,9 @@ __global__ void k_prune_zero(MapView m, int W, int epoch) {
   r -= 10;
   if (r < 45) { ncov_at(m, r, id) = 0.0; return; }
   r -= 45;
-  if (r < 3) { m.neval[(size_t)r * cp + id] = 0.0; return; }
+  if (r < 3) { neval_at(m, r, id) = 0.0; return; }
   r -= 3;
-  if (r < 9) { m.nevec[(size_t)r * cp + id] = 0.0; return; }
+  if (r < 9) { nevec_at(m, r, id) = 0.0; return; }
   r -= 9;
   if (r < 43) { m.nplane[(size_t)r * cp + id] = 0.0; return; }
   r -= 43;
@@ -1590,8 +1596,8 @@ __global__ void k_dump_leaves(MapView m, double *out, int max_leaves) {
   unpack_key(m.nkey[id], kx, ky, kz);
   o[0] = (double)kx; o[1] = (double)ky; o[2] = (double)kz; o[3] = m.nlayer[id]; o[4] = m.npath[id];
   o[5] = nadd_at(m, 9, id); o[6] = nfix_at(m, 9, id); o[7] = m.f_plane[id]; o[8] = m.f_exist[id]; o[9] = m.nopt[id];
-  for (int k = 0; k < 3; k++) o[10 + k] = m.neval[(size_t)k * cp + id];
-  for (int k = 0; k < 9; k++) o[13 + k] = m.nevec[(size_t)k * cp + id];
+  for (int k = 0; k < 3; k++) o[10 + k] = neval_at(m, k, id);
+  for (int k = 0; k < 9; k++) o[13 + k] = nevec_at(m, k, id);
   for (int k = 0; k < 10; k++) o[22 + k] = nadd_at(m, k, id);
   for (int k = 0; k < 7; k++) o[32 + k] = m.nplane[(size_t)k * cp + id];
 }
@@ -1802,7 +1808,7 @@ inline std::vector<DevArr> node_arrays(MapView &v, int W) {
       {(void **)&v.nseg_a, 4, (size_t)W}, {(void **)&v.nseg_b, 4, (size_t)W}, {(void **)&v.nsl, 4, 1}, {(void **)&v.ncnt, 4, 1}, {(void **)&v.nfb_head, 4, 1}, {(void **)&v.nfb_tail, 4, 1}, {(void **)&v.nlayer, 1, 1}, {(void **)&v.nstate, 1, 1}, {(void **)&v.f_exist, 1, 1},
       {(void **)&v.f_sw, 1, 1}, {(void **)&v.f_plane, 1, 1}, {(void **)&v.f_touched, 1, 1}, {(void **)&v.f_slide, 4, 1}, {(void **)&v.nql, 4, 1},
       {(void **)&v.ncenter, 8, 3}, {(void **)&v.njour, 8, 1}, {(void **)&v.nadd, 80, 1}, {(void **)&v.nfix, 80, 1}, {(void **)&v.ncov, 360, 1},
-      {(void **)&v.neval, 8, 3}, {(void **)&v.nevec, 8, 9}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, (size_t)80 * W, 1},
+      {(void **)&v.neval, 24, 1}, {(void **)&v.nevec, 72, 1}, {(void **)&v.nplane, 8, 43}, {(void **)&v.nlc, (size_t)80 * W, 1},
   };
 }
 inline std::vector<DevArr> scan_arrays(MapView &v, int W) {
