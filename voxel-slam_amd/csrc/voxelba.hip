@@ -62,9 +62,9 @@ const RcclApi &rccl_api() {
     RcclApi a;
     void *h = nullptr;
     if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;            // already in the process (e.g. torch's copy)
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) { const char *e = dlerror(); a.why = std::string("librccl.so.1 not found: ") + (e ? e : "?"); return a; }
     bool all = true;
     auto get = [&](const char *name) { void *s = dlsym(h, name); if (!s) { all = false; a.why = std::string("RCCL lacks ") + name; } return s; };
