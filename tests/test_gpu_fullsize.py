@@ -218,6 +218,59 @@ def test_fullsize_local_mapping_step_planes(capi, oracle, synth, scans):
     assert np.array_equal(gpv[:, 41:], oca_s), "cov_add after margi is not bit-identical"
 
 
+def test_fullsize_session_sums_stay_bit_identical(capi, oracle, synth):
+    """Five steady-state steps at full size (200k points per scan with covariances): multi_margi, slide, pvec_update + cut_voxel_multi,
+    multi_recut — both sides on identical poses, so that everything the map accumulates (pcr_add, pcr_fix counts, cov_add, through
+    fix_divide over the growing fixed-point chains and subdivide) can be compared bit for bit after every step."""
+    import dataclasses
+    wl = synth.CONFIGS["hesai200k_w10"]
+    W = wl.win_size
+    nstep = 5
+    traj = dataclasses.replace(wl, name=wl.name + "_traj%d" % (W + nstep), win_size=W + nstep)
+    s = synth.make_scans(traj)
+    x0 = synth.poses_flat(s["R0"], s["p0"])
+    ext = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
+    rng = np.random.default_rng(11)
+    A = rng.normal(0, 0.003, (15, 15)); cov = A @ A.T + np.eye(15) * 1e-6
+    ctx = capi.Context(_opts(capi, wl))
+    om = _omap(oracle, wl)
+    of = oracle.Factor(W)
+
+    def insert(slot, k):
+        state = np.zeros(25); state[1:10] = x0[k, :9]; state[10:13] = x0[k, 9:]
+        p_k, v_k = oracle.var_init(s["points"][k], ext, wl.dept_err, wl.beam_err)
+        v_w, _ = oracle.pvec_update(p_k, v_k, state, cov)
+        om.cut_voxel(slot, p_k, x0[k], var=v_w, multi=True)
+        ctx.pvec_update_cut_voxel(slot, p_k, v_k, x0[k], cov, multi=True)
+
+    def compare(tag):
+        g, _, _ = _sorted(ctx.dump_leaves()); gpv, _, _ = _sorted(ctx.dump_plane_var())     # (two dumps, each in its own order)
+        od = om.dump_leaves()
+        o, oca, _ = _sorted(od, om.dump_cov_add())
+        _assert_structure_equal(g, o)
+        assert np.array_equal(gpv[:, :5], o[:, :5])
+        assert np.array_equal(gpv[:, 41:], oca), tag + ": cov_add is not bit-identical"
+        return len(o)
+
+    for i in range(W):
+        insert(i, i)
+    window = x0[:W].copy()
+    ctx.recut(W, window, multi=True); om.recut(W, window, of, multi=True)
+    n0 = compare("window build")
+    last = W - 1
+    for step in range(nstep):
+        ctx.evaluate_only_residual(window); of.evaluate_only_residual(window)        # the eigen state margi copies (VM:1495-1501)
+        ctx.margi(W, window, jour=float(last)); om.margi(W, window, of, jour=float(last))
+        ctx.slide(1); om.slide(1)
+        last += 1
+        insert(W - 1, last)
+        window = x0[last - W + 1:last + 1].copy()
+        ctx.recut(W, window, multi=True); om.recut(W, window, of, multi=True)
+        assert ctx.size() == of.size()
+        n = compare("step %d" % step)
+    assert n > n0 > 20000
+
+
 def test_fullsize_rebuild_is_deterministic(capi, synth, scans):
     """No f64 atomics are left on the map path: two runs give the same bits for the structure, the cluster sums, the covariance sums,
     the eigen-pairs and the planes of every leaf.  The ORDER of the factors in the store still depends on the run (node ids and
