@@ -82,6 +82,7 @@ typedef struct vba_options {
   int hessian_compact_tiles;        /* != 0: Hessian pass on occupancy-compact tiles (k_hessian3, W <= 10) instead of dense fixed-size ones; measured slower at the bench size */
   size_t max_map_nodes;             /* map capacity hints (0 = grow on demand): octree nodes and fixed (marginalised) points the map is */
   size_t max_fix_points;            /* sized for at the first insertion — a session that stays below them never re-allocates (no stalls) */
+  int hba_workers;                  /* vba_hba_global on one rank: bottom-layer windows optimised side by side by this many worker contexts (0 = default 4, 1 = one after the other) */
 } vba_options;
 
 void vba_default_options(vba_options *opt); /* values of config/avia.yaml:26-47 */

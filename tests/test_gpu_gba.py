@@ -212,6 +212,14 @@ def test_hba_global_at_scale(oracle):
     np.testing.assert_allclose(top["edges"][:, 2:14], r2["edges"][:, 2:14], rtol=0, atol=1e-6)
     np.testing.assert_allclose(top["edges"][:, 14:], r2["edges"][:, 14:], rtol=1e-4)
     ctx.close()
+    # the run above optimised the 39 windows on 4 worker contexts side by side (vba_options::hba_workers, default); one after the other:
+    o1w = capi.options_from_workload(dataclasses.replace(wl, win_size=wd)); o1w.hba_workers = 1
+    ctx1 = capi.Context(o1w)
+    s1, s2 = ctx1.hba_global(clouds, x0, x0, GBA["gba_voxel_size"], GBA["gba_min_eigen_value"], GBA["gba_eig"], 2, wd, mg)
+    ctx1.close()
+    assert s1.shape == e1.shape and s2.shape == e2.shape and np.array_equal(s1[:, :2], e1[:, :2]) and np.array_equal(s2[:, :2], e2[:, :2])
+    np.testing.assert_allclose(s1[:, 2:14], e1[:, 2:14], rtol=0, atol=1e-6)    # (the GBA octree sums with f64 atomics: two runs agree to the bar of the oracle comparison above)
+    np.testing.assert_allclose(s2[:, 2:14], e2[:, 2:14], rtol=0, atol=1e-6)
 
 
 def test_hba_global_full_length():

@@ -42,7 +42,7 @@ class Options(C.Structure):
         ("imu_coef", C.c_double), ("thread_num", C.c_int), ("device", C.c_int), ("stream", C.c_void_p),
         ("max_voxels", C.c_size_t), ("max_points_per_scan", C.c_size_t),
         ("lm_spec", C.c_int), ("force_collective", C.c_int), ("hessian_workgroups", C.c_int), ("residual_vpl_from", C.c_int), ("hessian_compact_tiles", C.c_int),
-        ("max_map_nodes", C.c_size_t), ("max_fix_points", C.c_size_t),
+        ("max_map_nodes", C.c_size_t), ("max_fix_points", C.c_size_t), ("hba_workers", C.c_int),
     ]
 
 
@@ -447,8 +447,12 @@ class Context:
                     resis=rl[:nl.value].copy())
 
     def hba_global(self, clouds, poses_x0, poses_now, gba_voxel_size, gba_min_eigen_value, gba_eig, total_max_iter, wdsize=10, mgsize=5):
-        n = len(clouds)
-        off, pnt = self._ragged(clouds)
+        if isinstance(clouds, tuple):                # (offsets[n + 1], points[N][3]) already concatenated by the caller
+            off, pnt = clouds
+            n = len(off) - 1
+        else:
+            n = len(clouds)
+            off, pnt = self._ragged(clouds)
         nwin = max(0, (n - wdsize) // mgsize + 1) if n >= wdsize else 0
         cap1 = nwin * (wdsize * (wdsize - 1) // 2) + 1; cap2 = nwin * (nwin - 1) // 2 + 1
         e1 = np.zeros((cap1, 20)); e2 = np.zeros((cap2, 20)); n1 = C.c_int(0); n2 = C.c_int(0)

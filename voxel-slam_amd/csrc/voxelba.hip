@@ -23,7 +23,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include <array>
 #include <map>
@@ -163,6 +165,7 @@ struct vba_ctx {
   double *d_lipack = nullptr; size_t lipack_doubles = 0;       // li_ba_device: results gathered for one D2H copy
   double *d_liscr = nullptr; size_t liscr_doubles = 0;         // k_li_solve at W > 10: staged matrix / L outside the LDS
   double *d_hba_all = nullptr; size_t hba_all_doubles = 0;   // vba_hba_global: keyframe clouds + submap clouds, kept across calls
+  std::vector<vba_ctx *> hba_workers;                         // vba_hba_global: extra contexts (own stream, own octree) that optimise bottom-layer windows side by side
 
   void set_error(const std::string &s) { err = s; }
 };
@@ -628,6 +631,8 @@ void vba_destroy(vba_ctx *c) {
   map_free(c->map);
   c->gba.free_all();
   c->big.release();
+  for (vba_ctx *w : c->hba_workers) vba_destroy(w);
+  c->hba_workers.clear();
   if (c->d_hba_all) hipFree(c->d_hba_all);
   if (c->d_lipack) hipFree(c->d_lipack);
   if (c->d_liscr) hipFree(c->d_liscr);
@@ -1553,13 +1558,19 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   // enters both collectives and all of them return the same error afterwards — no rank is left waiting in a collective.
   // The top-level window then runs replicated (identical inputs on every rank).
   const bool replicas = c->collective() && c->n_ranks > 1;
-  const int NR = replicas ? c->n_ranks : 1;
   int n_win = 0;
   for (int start = 0; start + wdsize <= n_kf; start += mgsize) n_win++;
+  // ONE rank: the windows are independent problems too, and one window is a chain of small kernels and host round trips that leaves
+  // most of the chip idle — KL worker contexts (own stream, own octree and LM state; host threads drive them) optimise windows
+  // side by side, with the bookkeeping of the replicas: worker t takes windows t, t + KL, ... and writes their clouds into its chunk.
+  const int kl_opt = c->opt.hba_workers > 0 ? (c->opt.hba_workers < 8 ? c->opt.hba_workers : 8) : 4;
+  const int KL = (!replicas && n_win >= 2 * kl_opt) ? kl_opt : 1;
+  const bool local_rep = KL > 1, chunked = replicas || local_rep;
+  const int NR = replicas ? c->n_ranks : KL;
   const size_t meta_per = 3 + (size_t)(wdsize * (wdsize - 1) / 2) * 20;
-  const size_t win_per_rank = replicas ? (size_t)(n_win + NR - 1) / NR : 0, meta_chunk = meta_per * win_per_rank;
+  const size_t win_per_rank = chunked ? (size_t)(n_win + NR - 1) / NR : 0, meta_chunk = meta_per * win_per_rank;
   std::vector<size_t> rank_cap(NR, 0), win_roff(n_win > 0 ? n_win : 1, 0);      // points capacity per rank chunk, window offset inside it
-  if (replicas) {
+  if (chunked) {
     int w = 0;
     for (int start = 0; start + wdsize <= n_kf; start += mgsize, w++) {
       win_roff[w] = rank_cap[w % NR];
@@ -1568,7 +1579,7 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   }
   size_t chunk_pts = 0;
   for (int r = 0; r < NR; r++) if (rank_cap[r] > chunk_pts) chunk_pts = rank_cap[r];
-  if (!replicas) chunk_pts = 0;
+  if (!chunked) chunk_pts = 0;
   const size_t need = (n_all + n_sub_cap + (size_t)NR * chunk_pts) * 3 + (size_t)NR * meta_chunk + 64;
   if (need > c->hba_all_doubles) {
     if (c->d_hba_all) hipFree(c->d_hba_all);
@@ -1577,7 +1588,7 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
     c->hba_all_doubles = need;
   }
   double *d_all = c->d_hba_all, *d_sub = c->d_hba_all + n_all * 3;
-  if (n_all > 0) HIPCHK(c, hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream));
+  if (n_all > 0 && !local_rep) HIPCHK(c, hipMemcpyAsync(d_all, pnt_local, n_all * 3 * sizeof(double), hipMemcpyDefault, c->stream));   // (the worker path uploads in chunks, under the first windows)
   std::vector<int> ccnt(n_win_max > 0 ? n_win_max : 1);
   size_t sub_off = 0;
   double *d_rep = d_sub + n_sub_cap * 3, *d_meta = d_rep + (size_t)NR * chunk_pts * 3;      // replica mode only
@@ -1589,7 +1600,87 @@ int vba_hba_global(vba_ctx *c, int n_kf, const int *offsets, const double *pnt_l
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_g0 = want_times ? (hipStreamSynchronize(c->stream), now()) : 0.0;
   double t_g1 = 0;
-  for (int start = 0; start + wdsize <= n_kf; start += mgsize) {
+  if (local_rep) {
+    while ((int)c->hba_workers.size() < KL - 1) {
+      vba_options o = c->opt; o.stream = nullptr; o.device = c->device;
+      vba_ctx *w = nullptr;
+      const int stc = vba_create(&o, &w);
+      if (stc) { c->set_error("vba_hba_global: could not create a worker context"); return stc; }
+      c->hba_workers.push_back(w);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int w = 0; w < n_win; w++) meta[(size_t)(w % KL) * meta_chunk + meta_per * (size_t)(w / KL) + 2] = -1.0;   // "not run"
+    std::vector<std::string> werr(KL);
+    // the keyframe clouds travel to HBM in chunks on a stream of their own while the first windows are already being optimised
+    // (2.4 GB at full length: as long as the windows themselves); a window starts when its keyframes have arrived
+    std::atomic<int> kf_ready{0}, give_up{0};
+    auto work = [&](int tw) {
+      vba_ctx *cx = tw == 0 ? c : c->hba_workers[tw - 1];
+      hipSetDevice(c->device);
+      std::vector<double> ed(edges.size());
+      std::vector<int> cc(ccnt.size()), off(wdsize + 1);
+      for (int w = tw; w < n_win; w += KL) {
+        const int start = w * mgsize;
+        while (kf_ready.load(std::memory_order_acquire) < start + wdsize && !give_up.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (give_up.load()) return;
+        for (int i = 0; i <= wdsize; i++) off[i] = offsets[start + i] - offsets[start];
+        std::vector<double> xs(poses_x0 + (size_t)start * 12, poses_x0 + (size_t)(start + wdsize) * 12);
+        int ne = 0, nc = 0;
+        double *mrec = &meta[(size_t)tw * meta_chunk + meta_per * (size_t)(w / KL)];
+        const int st = vba_hba_add_edge(cx, wdsize, off.data(), d_all + (size_t)offsets[start] * 3, xs.data(), gba_voxel_size, gba_min_eigen_value,
+                                        gba_eigen_value_array, 1, 2, ed.data(), &ne, d_rep + ((size_t)tw * chunk_pts + win_roff[w]) * 3,
+                                        cc.data(), &nc, nullptr, nullptr);
+        mrec[2] = st;
+        if (st != VBA_OK) { werr[tw] = cx->err; return; }
+        mrec[0] = nc; mrec[1] = ne;
+        std::memcpy(mrec + 3, ed.data(), (size_t)ne * 20 * sizeof(double));
+      }
+    };
+    int up_status = VBA_OK;
+    {
+      std::vector<std::thread> th;
+      for (int tw = 0; tw < KL; tw++) th.emplace_back(work, tw);
+      // (one uploader: three threads staging chunks in turn moved the pageable copy no faster — 4-5 GB/s either way; at full
+      //  length the call is bound by this copy once the windows overlap it)
+      hipStream_t up = nullptr;
+      if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) { up_status = VBA_ERR_HIP; give_up.store(1); }
+      const int CH = 16;                                                           // keyframes per chunk
+      for (int k0 = 0; k0 < n_kf && up_status == VBA_OK; k0 += CH) {
+        const int k1 = k0 + CH < n_kf ? k0 + CH : n_kf;
+        const size_t o0 = (size_t)offsets[k0] * 3, nb = (size_t)(offsets[k1] - offsets[k0]) * 3 * sizeof(double);
+        if (nb > 0 && (hipMemcpyAsync(d_all + o0, pnt_local + o0, nb, hipMemcpyDefault, up) != hipSuccess || hipStreamSynchronize(up) != hipSuccess)) {
+          up_status = VBA_ERR_HIP; give_up.store(1); break;
+        }
+        kf_ready.store(k1, std::memory_order_release);
+      }
+      if (up) hipStreamDestroy(up);
+      for (auto &x : th) x.join();
+    }
+    hipSetDevice(c->device);
+    if (up_status != VBA_OK) { c->set_error("vba_hba_global: uploading the keyframe clouds failed"); return up_status; }
+    for (int w = 0; w < n_win; w++) {                                            // the first failing window in window order decides
+      const int stw = (int)meta[(size_t)(w % KL) * meta_chunk + meta_per * (size_t)(w / KL) + 2];
+      if (stw > 0) { if (!werr[w % KL].empty()) c->set_error(werr[w % KL]); return stw; }
+    }
+    for (int w = 0; w < n_win; w++) {
+      const double *mrec = &meta[(size_t)(w % KL) * meta_chunk + meta_per * (size_t)(w / KL)];
+      if ((int)mrec[2] != VBA_OK) { c->set_error("vba_hba_global: a bottom-layer window was not run"); return VBA_ERR_HIP; }
+      const int nc = (int)mrec[0], ne = (int)mrec[1], start = w * mgsize;
+      for (int e = 0; e < ne; e++) {
+        if (*n_edges1 >= cap1) return VBA_ERR_CAPACITY;
+        double *o = edges1_out + (size_t)(*n_edges1) * 20;
+        std::memcpy(o, mrec + 3 + (size_t)e * 20, 20 * sizeof(double));
+        o[0] += start; o[1] += start;
+        (*n_edges1)++;
+      }
+      if (nc > 0) HIPCHK(c, hipMemcpyAsync(d_sub + sub_off * 3, d_rep + ((size_t)(w % KL) * chunk_pts + win_roff[w]) * 3, (size_t)nc * 3 * sizeof(double),
+                                           hipMemcpyDeviceToDevice, c->stream));
+      sub_first.push_back(start);
+      sub_n.push_back(nc);
+      sub_off += (size_t)nc;
+    }
+  }
+  for (int start = 0; !local_rep && start + wdsize <= n_kf; start += mgsize) {
     std::vector<int> off(wdsize + 1);
     for (int i = 0; i <= wdsize; i++) off[i] = offsets[start + i] - offsets[start];
     std::vector<double> xs(poses_x0 + (size_t)start * 12, poses_x0 + (size_t)(start + wdsize) * 12);
