@@ -114,34 +114,33 @@ __device__ void li_imu_body(const LmDev *s, LiDev *li, const double *imu, double
     for (int k = 0; k < 15; k++) a += jf[k * nb] * cf[k * nb];
     return a;
   };
-  // state blocks in 3 x 3 register tiles: task = (block pair (a, b), tile); <= 2 factors contribute, ascending
+  // state blocks on the matrix cores: a wave owns a 15 x 15 block pair (a, b); J_f^T (cov^-1 J_f) restricted to the block's rows and
+  // columns is one 16 x 16 tile with K = 15 (four v_mfma_f64_16x16x4_f64, the 16th k padded with zeros); the <= 2 factors of a
+  // diagonal block accumulate in ascending order in the same tile.  (As 3 x 3 register tiles on the VALU this was 19.6 of the
+  // workgroup's 32 us: 540 LDS loads per thread.)
   {
-    const int npair = 3 * W - 2;
-    for (int t = tid; t < npair * 25; t += NTH) {
-      const int pr = t / 25, tile = t - 25 * pr, r0 = 3 * (tile / 5), c0 = 3 * (tile % 5);
+    typedef double li_v4f64 __attribute__((ext_vector_type(4)));
+    const int npair = 3 * W - 2, lane = tid & 63, wv = tid >> 6, nwv = NTH >> 6, m = lane & 15, kq = lane >> 4;
+    for (int pr = wv; pr < npair; pr += nwv) {
       const int a = (pr + 1) / 3, b = a + ((pr + 1) % 3) - 1;
-      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      li_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
       for (int pass = 0; pass < 2; pass++) {
         int f, ro, co;
         if (b == a) { if (pass == 0) { f = a - 1; ro = 15; co = 15; } else { f = a; ro = 0; co = 0; } }
         else if (b == a + 1) { if (pass) continue; f = a; ro = 0; co = 15; }
         else { if (pass) continue; f = b; ro = 15; co = 0; }
         if (f < 0 || f >= F) continue;
-        const double *jf = joc + (size_t)f * 15 * nb + ro + r0, *cf = cj + (size_t)f * 15 * nb + co + c0;
-#pragma unroll 5
-        for (int k = 0; k < 15; k++) {
-          const double j0 = jf[k * nb], j1 = jf[k * nb + 1], j2 = jf[k * nb + 2];
-          const double q0 = cf[k * nb], q1 = cf[k * nb + 1], q2 = cf[k * nb + 2];
-          acc[0][0] += j0 * q0; acc[0][1] += j0 * q1; acc[0][2] += j0 * q2;
-          acc[1][0] += j1 * q0; acc[1][1] += j1 * q1; acc[1][2] += j1 * q2;
-          acc[2][0] += j2 * q0; acc[2][1] += j2 * q1; acc[2][2] += j2 * q2;
+        const double *jf = joc + (size_t)f * 15 * nb + ro + m, *cf = cj + (size_t)f * 15 * nb + co + m;   // (lane 15 of a row reads a neighbour: its products only reach the discarded row / column 15)
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+          const int k = k0 + kq;
+          const double av = k < 15 ? jf[k * nb] : 0.0, bv = k < 15 ? cf[k * nb] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
       }
-      double *o = himu + li_hb_pair(a, b) + 15 * r0 + c0;
+      double *o = himu + li_hb_pair(a, b);
 #pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) o[15 * r + c] = acc[r][c];
+      for (int r = 0; r < 4; r++) { const int row = kq + 4 * r; if (row < 15 && m < 15) o[15 * row + m] = acc[r]; }
     }
   }
   if (grav) {                                                // gravity border VM:788-795 and the 3 x 3 corner
