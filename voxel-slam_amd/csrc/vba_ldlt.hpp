@@ -68,25 +68,29 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
     double *Lk = Lst + C::lst_off(kb);
     __syncthreads();
     if (stamps && tid == 0 && kb < 20) stamps[8 + 2 * kb] = clock64();
-    if (tid < NP && tid >= k0) {
-      const int i = tid, ib = i - k0;
-      double D[8][8], x[8];
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-#pragma unroll
-        for (int c = 0; c <= r; c++) D[r][c] = P[(k0 + r) * 8 + c];
+    if ((tid | 63) >= k0 && (tid & ~63) < NP) {               // wave-uniform: some lane of this wave owns a row of the trailing matrix
+      // The 8 x 8 diagonal block is factorised ONCE PER WAVE, spread over its lanes: lane r < 8 keeps row r of the block, a pivot and
+      // the scaled pivot column reach the other lanes by v_readlane (no LDS, no barrier).  Every row lane used to factorise the
+      // block redundantly in its own registers (~430 f64 instructions per panel, the constant 2.6-2.9k cycles of DESIGN.md 5/9);
+      // the arithmetic per element is unchanged, so the factor is bit-identical.
+      const bool rowlane = tid < NP && tid >= k0;
+      const int i = rowlane ? tid : k0, ib = i - k0;
+      double Dr[8], x[8];
       {
+        const double *dr = P + (k0 + (l & 7)) * 8;
+        const double2 d0 = *reinterpret_cast<const double2 *>(dr), d1 = *reinterpret_cast<const double2 *>(dr + 2),
+                      d2 = *reinterpret_cast<const double2 *>(dr + 4), d3 = *reinterpret_cast<const double2 *>(dr + 6);
+        Dr[0] = d0.x; Dr[1] = d0.y; Dr[2] = d1.x; Dr[3] = d1.y; Dr[4] = d2.x; Dr[5] = d2.y; Dr[6] = d3.x; Dr[7] = d3.y;
         const double2 x0 = *reinterpret_cast<const double2 *>(P + i * 8), x1 = *reinterpret_cast<const double2 *>(P + i * 8 + 2),
                       x2 = *reinterpret_cast<const double2 *>(P + i * 8 + 4), x3 = *reinterpret_cast<const double2 *>(P + i * 8 + 6);
         x[0] = x0.x; x[1] = x0.y; x[2] = x1.x; x[3] = x1.y; x[4] = x2.x; x[5] = x2.y; x[6] = x3.x; x[7] = x3.y;
       }
-      const bool is_rhs = (i == rhs_row);
+      const bool is_rhs = rowlane && (i == rhs_row);
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        // pivot c of the diagonal block (identical in every lane).  f64 dependent-issue latency is ~40 cycles here, so the
-        // recurrence is arranged to keep the chain pivot -> next pivot short: 1/d by v_rcp_f64 and two Newton steps in
-        // three levels (e^2 is formed beside y1), every update as fma(-(a b), 1/d, .) with the product a b off the chain.
-        const double d = D[c][c];
+        // pivot c of the diagonal block.  f64 dependent-issue latency is ~40 cycles here, so the recurrence is arranged to keep
+        // the chain pivot -> next pivot short: 1/d by v_rcp_f64 and two Newton steps in three levels (e^2 is formed beside y1)
+        const double d = readlane_f64(Dr[c], c);
         const bool ok = fabs(d) > 0.0;
         const double y0 = __builtin_amdgcn_rcp(d);
         const double e = fma(-d, y0, 1.0);
@@ -98,19 +102,14 @@ __device__ __forceinline__ void ldlt_mfma(double *__restrict__ Lst, double *__re
         if (is_rhs) lv = (fabs(d) > 2.2250738585072014e-308) ? x[c] * dinv : 0.0;
         lv = (ib > c) ? lv : 0.0;               // rows of the diagonal block: strictly lower part only
         const double tmc = (ok && ib > c) ? x[c] : 0.0;   // T = L d = the unscaled value (0 for a zero pivot)
-        Lk[ib * LS + c] = lv;
-        Tp[i * LS + c] = -tmc;
-        // the panel step is issue-bound (one wave per SIMD, ~4 cycles per f64 instruction): scale the column once
-        // (7 - c multiplications) so that every update is a single FMA
-        double Lc[8];
+        if (rowlane) { Lk[ib * LS + c] = lv; Tp[i * LS + c] = -tmc; }
+        const double lrc = Dr[c] * dinv;        // lane r: L[r][c] of the block (0 for a zero pivot: no update)
 #pragma unroll
-        for (int r = c + 1; r < 8; r++) Lc[r] = D[r][c] * dinv;                          // L[r][c] of the block (0 for a zero pivot: no update)
-#pragma unroll
-        for (int c2 = c + 1; c2 < 8; c2++) x[c2] = fma(-tmc, Lc[c2], x[c2]);
-#pragma unroll
-        for (int r = c + 1; r < 8; r++)
-#pragma unroll
-          for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] = fma(-D[r][c], Lc[c2], D[r][c2]);
+        for (int c2 = c + 1; c2 < 8; c2++) {
+          const double Lc2 = readlane_f64(lrc, c2);
+          x[c2] = fma(-tmc, Lc2, x[c2]);
+          Dr[c2] = fma(-Dr[c], Lc2, Dr[c2]);
+        }
       }
     }
     __syncthreads();
