@@ -1,5 +1,7 @@
 """How close are the map's sums to the CPU oracle's, bit for bit?  Prints the number of leaves whose pcr_add / cov_add differ at all
-and the largest relative difference, after the inserts, after the recut and after a marginalisation + next scan."""
+and the largest relative difference, after the inserts, after the recut and after a marginalisation + next scan.
+TEST INFRASTRUCTURE (a parity checker too long for the suite): like tests/, it uses the CPU oracle as the CHECKER of the device results, never as a
+part of the path it measures."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,6 @@
-"""Top-level HBA_add_edge at W = 60 submaps (sparse path) vs the CPU port."""
+"""Top-level HBA_add_edge at W = 60 submaps (sparse path) vs the CPU port.
+TEST INFRASTRUCTURE (a timing comparison too long for the suite): like tests/, it uses the CPU oracle as the CHECKER of the device results, never as a
+part of the path it measures."""
 import sys, os, time, dataclasses
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

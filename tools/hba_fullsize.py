@@ -1,7 +1,9 @@
 """BASELINE.json configs[4] at FULL length on one GPU: `nkf` keyframes x 50k points through vba_hba_global (bottom-layer windows of
 10 every 5 + the top-level BA over the submaps), with the bottom layer checked against the CPU oracle on a sample of windows.
     python tools/hba_fullsize.py [nkf=2000] [oracle_windows=12]
-(too long for the test-suite: the 200-keyframe case is tests/test_gpu_gba.py::test_hba_global_at_scale)"""
+(too long for the test-suite: the 200-keyframe case is tests/test_gpu_gba.py::test_hba_global_at_scale)
+TEST INFRASTRUCTURE (a parity checker too long for the suite): like tests/, it uses the CPU oracle as the CHECKER of the device results, never as a
+part of the path it measures."""
 import dataclasses, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -4,17 +4,18 @@ the kernel sequence of one scan from the trace."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import voxel_slam_amd  # noqa
 from voxel_slam_amd import capi, synth
-import oracle_api as oracle
 
 wl = synth.CONFIGS["hesai200k_w10"]
 s = synth.make_scans(wl); W = wl.win_size
 poses = synth.poses_flat(s["R0"], s["p0"])
 ext = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
 cov = np.eye(15) * 1e-6
-pv = [oracle.var_init(s["points"][i], ext, wl.dept_err, wl.beam_err) for i in range(W)]
+_c0 = capi.Context(capi.options_from_workload(wl))
+pv = [_c0.var_init(s["points"][i], ext, wl.dept_err, wl.beam_err) for i in range(W)]      # body-frame covariances on the device (k_var_init)
+_c0.close()
 for with_var in (True, False):
     ctx = capi.Context(capi.options_from_workload(wl))
     for i in range(W):
