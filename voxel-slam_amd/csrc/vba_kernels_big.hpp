@@ -247,6 +247,8 @@ struct GbaBigView {
   unsigned long long *ekeys; unsigned int emask; double *ecl;   // [10][emask + 1]
   // points
   double *pw; const double *pl; int *pframe, *pnode;
+  int *perm;                   // points ordered by root voxel (the accumulation pass walks them in this order: see k_gbab_accum)
+  unsigned int *skey; int *sval;   // sort input: root id (all ones = no root) / point index
   int *cnt; double *poses; int *offsets;
 };
 
@@ -286,9 +288,16 @@ __global__ void k_gbab_rootid(GbaBigView g) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= g.npts) return;
   const int s = g.pnode[p];
-  if (s >= 0) g.pnode[p] = g.hvals[s];
+  const int id = s >= 0 ? g.hvals[s] : -1;
+  if (s >= 0) g.pnode[p] = id;
+  g.skey[p] = id >= 0 ? (unsigned int)id : (unsigned int)g.cap;      // "no root" sorts behind every id
+  g.sval[p] = p;
 }
-// (LDS pre-aggregation per (node, frame) as k_gba_accum; the global (node, frame) table is probed once per occupied LDS entry)
+// (LDS pre-aggregation per (node, frame) as k_gba_accum; the global (node, frame) table is probed once per occupied LDS entry).
+// The points are walked in ROOT-VOXEL order (perm, one radix sort per build): the clouds of a top-level window arrive submap by
+// submap in the down-sampler's hash order, so 256 consecutive points touched ~150 different (node, frame) pairs and the pass was
+// bound by L2 atomic throughput (8 M points: 6-15 ms per level, 92 of the 187 ms of a 199-submap window); in root order a
+// workgroup sees a handful of pairs.
 __global__ __launch_bounds__(256) void k_gbab_accum(GbaBigView g) {
   __shared__ unsigned long long tkey[256];   // 256 points per workgroup -> at most 256 keys; 42 KB keeps three workgroups per CU
   __shared__ unsigned int tslot[256];
@@ -297,9 +306,10 @@ __global__ __launch_bounds__(256) void k_gbab_accum(GbaBigView g) {
   tkey[tid] = ~0ull;
   for (int t = tid; t < 20 * 256; t += 256) (&tacc[0][0])[t] = 0.0;
   __syncthreads();
-  const int p = blockIdx.x * blockDim.x + tid;
+  const int q = blockIdx.x * blockDim.x + tid;
   const size_t n = (size_t)g.npts, cp = (size_t)g.cap, ct = (size_t)g.emask + 1;
-  if (p < g.npts) {
+  if (q < g.npts) {
+    const int p = g.perm[q];
     const int id = g.pnode[p];
     if (id >= 0) {
       const unsigned int e = gba_lds_claim(tkey, ((unsigned long long)(unsigned int)id << 20) | (unsigned int)g.pframe[p]);
@@ -577,6 +587,7 @@ __global__ void k_bigl_bs_out(const double *__restrict__ Ab, int NP, int ld, int
 }
 
 struct BigStore {
+  int last_cap = 1 << 17;
   BigView b{};
   GbaBigView g{};
   // Device memory comes from an arena of large chunks that survives across builds (reset() rewinds it): hipMalloc / hipFree
@@ -621,10 +632,16 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
   BIGCHK(al((void **)&g.hkeys, (size_t)hcap * 8)); BIGCHK(al((void **)&g.hvals, (size_t)hcap * 4));
   BIGCHK(al((void **)&g.ekeys, (size_t)ecap * 8)); BIGCHK(al((void **)&g.ecl, (size_t)ecap * 10 * 8));
   BIGCHK(al((void **)&g.pw, (size_t)n * 3 * 8)); BIGCHK(al((void **)&g.pframe, (size_t)n * 4)); BIGCHK(al((void **)&g.pnode, (size_t)n * 4));
+  unsigned int *skey_b = nullptr; void *sort_tmp = nullptr; size_t sort_bytes = 0;
+  BIGCHK(al((void **)&g.skey, (size_t)n * 4)); BIGCHK(al((void **)&skey_b, (size_t)n * 4)); BIGCHK(al((void **)&g.sval, (size_t)n * 4)); BIGCHK(al((void **)&g.perm, (size_t)n * 4));
+  if (n > 0) {
+    BIGCHK(sort_pairs_u32(nullptr, sort_bytes, g.skey, skey_b, g.sval, g.perm, (size_t)n, 32u, st));
+    BIGCHK(al(&sort_tmp, sort_bytes + 256));
+  }
   BIGCHK(al((void **)&g.cnt, GCNT_N * sizeof(int))); BIGCHK(al((void **)&g.poses, (size_t)W * 12 * 8)); BIGCHK(al((void **)&g.offsets, (size_t)(W + 1) * 4));
   BIGCHK(hipMemcpyAsync(g.poses, poses, (size_t)W * 12 * 8, hipMemcpyHostToDevice, st));
   BIGCHK(hipMemcpyAsync(g.offsets, offsets, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
-  int cap = 1 << 17;
+  int cap = s.last_cap;                          // (the node capacity the previous build ended with: no doubling attempts, each of which re-clears the tables)
   const dim3 bk(256), gp((n + 255) / 256);
   for (int attempt = 0; attempt < 10; attempt++) {
     const size_t cp = (size_t)cap;
@@ -642,10 +659,18 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
       hipLaunchKernelGGL(k_gbab_keys, gp, bk, 0, st, g, P);
       hipLaunchKernelGGL(k_gbab_roots, dim3((hcap + 4095) / 4096), bk, 0, st, g, P);
       hipLaunchKernelGGL(k_gbab_rootid, gp, bk, 0, st, g);
+      {
+        unsigned int bits = 1; while (bits < 32 && (1ull << bits) <= (unsigned long long)cap) bits++;     // keys are <= cap
+        size_t tb = sort_bytes + 256;
+        BIGCHK(sort_pairs_u32(sort_tmp, tb, g.skey, skey_b, g.sval, g.perm, (size_t)n, bits, st));
+      }
       for (int L = 0; L <= P.max_layer; L++) {
         // entries of the previous level are dead: a planar node keeps its own entries (it stopped descending), so the
         // table is only cleared of nothing here — finished nodes never receive points again and their keys stay valid
-        if (L == 0) { BIGCHK(hipMemsetAsync(g.ekeys, 0xFF, (size_t)ecap * 8, st)); BIGCHK(hipMemsetAsync(g.ecl, 0, (size_t)ecap * 10 * 8, st)); }
+        if (L == 0) {   // (a fill kernel: the runtime's memset moved the 5.4 GB of an 8 M-point window at 750 GB/s, 7.2 ms a time)
+          hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, st, g.ekeys, ~0ull, (size_t)ecap);
+          hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, st, (unsigned long long *)g.ecl, 0ull, (size_t)ecap * 10);
+        }
         hipLaunchKernelGGL(k_gbab_accum, gp, bk, 0, st, g);
         hipLaunchKernelGGL(k_gbab_decide, dim3((cap + 255) / 256), bk, 0, st, g, P, L);
         if (L < P.max_layer) hipLaunchKernelGGL(k_gbab_descend, gp, bk, 0, st, g);
@@ -656,7 +681,7 @@ inline int big_build(BigStore &s, hipStream_t st, int W, const int *offsets, con
     BIGCHK(hipMemcpyAsync(s.h_cnt, g.cnt, GCNT_N * sizeof(int), hipMemcpyDeviceToHost, st));
     BIGCHK(hipStreamSynchronize(st));
     if (s.h_cnt[GCNT_OVERFLOW] == 2) { err = "keyframe point outside the 21-bit voxel index range"; return VBA_ERR_CAPACITY; }
-    if (!s.h_cnt[GCNT_OVERFLOW]) break;
+    if (!s.h_cnt[GCNT_OVERFLOW]) { s.last_cap = cap; break; }
     // (the undersized node arrays stay in the arena until the next build rewinds it)
     cap *= 2;
     if (attempt == 9) { err = "octree node capacity"; return VBA_ERR_CAPACITY; }
