@@ -91,11 +91,6 @@ void vba_destroy(vba_ctx *ctx);
 const char *vba_status_string(int status);
 const char *vba_last_error(vba_ctx *ctx);
 int vba_synchronize(vba_ctx *ctx);
-/* Page-lock a host buffer the caller keeps handing in (the keyframe clouds of vba_hba_global, scans): a copy from pageable memory is
- * staged by the runtime at 4-5 GB/s, from pinned memory it is a DMA transfer.  No reference counterpart (the reference never leaves the
- * host); the buffer stays the caller's.  vba_host_unpin before it is freed. */
-int vba_host_pin(void *ptr, size_t bytes);
-int vba_host_unpin(void *ptr);
 
 /* ------------------------------------------------------------------------------------------------
  * Factor level — drop-in for class LidarFactor (VM:124-339).

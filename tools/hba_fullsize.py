@@ -38,9 +38,6 @@ runs = []
 t1 = time.time()
 ragged = ctx._ragged(clouds)          # offsets + one [N][3] array: what the C entry point takes (the node keeps its clouds that way)
 print("python harness: clouds concatenated in %.2f s (outside the timed call)" % (time.time() - t1), flush=True)
-t1 = time.time()
-capi.host_pin(ragged[1])              # the node keeps its keyframe clouds in one arena it pins once (vba_host_pin)
-print("arena of %.2f GB page-locked in %.2f s (once per session, outside the timed call)" % (ragged[1].nbytes / 1e9, time.time() - t1), flush=True)
 for rep in range(3):
     t1 = time.time()
     e1, e2 = ctx.hba_global(ragged, x0, x0, GBA["gba_voxel_size"], GBA["gba_min_eigen_value"], GBA["gba_eig"], 2, wd, mg)
@@ -72,6 +69,6 @@ if len(sys.argv) > 3:        # record for bench.py (profiles/rNN_hba_fullsize.js
                "seconds_per_call": float(min(runs[1:])), "runs_s": runs, "bottom_edges": int(len(e1)), "top_edges": int(len(e2)),
                "keyframes_per_s": nkf / float(min(runs[1:])),
                "oracle_check": {"windows": len(starts), "relative_pose_max_abs": float(worst_p), "edge_weight_q99_rel": float(worst_w)},
-               "what": "vba_hba_global wall time, host clouds (one page-locked arena, vba_host_pin) uploaded inside the call; measured by tools/hba_fullsize.py on the GPU box"},
+               "what": "vba_hba_global wall time, host clouds (one concatenated array) uploaded inside the call; measured by tools/hba_fullsize.py on the GPU box"},
               open(sys.argv[3], "w"), indent=1)
 print("OK")

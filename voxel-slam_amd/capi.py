@@ -21,7 +21,7 @@ OK = 0
 ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED_WINDOW, ERR_TOO_FEW_VOXELS, ERR_OPT_STATE, ERR_HIP, ERR_CAPACITY, ERR_IO, ERR_UNSUPPORTED = range(1, 10)
 
 EXPORTS = [
-    "vba_default_options", "vba_create", "vba_destroy", "vba_status_string", "vba_last_error", "vba_synchronize", "vba_host_pin", "vba_host_unpin",
+    "vba_default_options", "vba_create", "vba_destroy", "vba_status_string", "vba_last_error", "vba_synchronize",
     "vba_factor_clear", "vba_factor_push_voxels", "vba_factor_size", "vba_factor_acc_evaluate2",
     "vba_factor_evaluate_only_residual", "vba_factor_read_back", "vba_factor_occupied_slots", "vba_factor_occupancy_masks",
     "vba_lidar_ba_damping_iter", "vba_li_ba_damping_iter", "vba_last_lm_trace",
@@ -113,19 +113,6 @@ def options_from_workload(wl, stream=None) -> Options:
     if stream is not None:
         o.stream = stream
     return o
-
-
-def host_pin(arr) -> None:
-    """Page-lock a contiguous numpy array the caller keeps handing in (vba_host_pin); host_unpin before it is released."""
-    st = load().vba_host_pin(C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes))
-    if st:
-        raise VbaError(st)
-
-
-def host_unpin(arr) -> None:
-    st = load().vba_host_unpin(C.c_void_p(arr.ctypes.data))
-    if st:
-        raise VbaError(st)
 
 
 def shard_owner(key3, n_ranks: int) -> int:

@@ -660,14 +660,6 @@ void vba_destroy(vba_ctx *c) {
 
 const char *vba_last_error(vba_ctx *c) { return c ? c->err.c_str() : ""; }
 int vba_synchronize(vba_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return VBA_OK; }
-int vba_host_pin(void *ptr, size_t bytes) {
-  if (!ptr || bytes == 0) return VBA_ERR_BAD_ARG;
-  return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? VBA_OK : VBA_ERR_HIP;
-}
-int vba_host_unpin(void *ptr) {
-  if (!ptr) return VBA_ERR_BAD_ARG;
-  return hipHostUnregister(ptr) == hipSuccess ? VBA_OK : VBA_ERR_HIP;
-}
 
 // ---------------------------------------------------------------- factor level
 int vba_factor_clear(vba_ctx *c) { c->nvox = 0; return VBA_OK; }
